@@ -1,0 +1,83 @@
+"""ctypes binding of libgdm_hip.so (the C ABI declared in include/gdm.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails,
+this module raises.  `build()` compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgdm_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+
+class KnnJob(ctypes.Structure):
+    """struct gdm_knn_job (include/gdm.h)."""
+    _fields_ = [("support", _vp), ("query", _vp), ("idx", _vp), ("d2", _vp),
+                ("support_bstride", ctypes.c_int64), ("query_bstride", ctypes.c_int64),
+                ("S", ctypes.c_int32), ("Q", ctypes.c_int32), ("K", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/gdm.h declares
+SIGNATURES = {
+    "gdm_last_error": (ctypes.c_char_p, []),
+    "gdm_version": (_i, []),
+    "gdm_knn_batch": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "gdm_knn_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gdm_knn_jobs_hip": (_i, [ctypes.POINTER(KnnJob), _i, _i, _vp]),
+    "gdm_ballquery_hip": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "gdm_furthestsampling_hip": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gdm_group_gather_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_group_gather_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_gather_max_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gdm_gather_max_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_gather_nn_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_gather_nn_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_rel_pos_enc_hip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gdm_att_pool_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_att_pool_bwd_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gdm_match_workspace_bytes": (_sz, [_i, _i, _i]),
+    "gdm_match_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of libgdm_hip.so (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libgdm_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C geometric_aware_dense_matching_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class GdmError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gdm_last_error()
+        raise GdmError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

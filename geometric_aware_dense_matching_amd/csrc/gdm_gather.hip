@@ -1,0 +1,329 @@
+// Feature gather / pool / scatter kernels of the RandLA point branch and the RGB<->point fusion,
+// gfx950 (MI355X).  All are HBM/L2-bound byte movers: no MFMA, no LDS tiling needed -- what
+// matters is that index rows are read once per output point (not once per channel, as the
+// reference's `index.repeat(1, C, 1)` + torch.gather does) and that every global access of a
+// wave is contiguous along the innermost (point / neighbour) axis.
+//
+// Reference chains replaced (/root/reference):
+//   group_gather   models/RandLA/RandLANet.py:729-738 gather_neighbour (+ permute :704-716)
+//   gather_max     models/ffb6d.py:128-146 random_sample
+//   gather_nn      models/ffb6d.py:148-163 nearest_interpolation, :278-281 choose gather
+//   rel_pos_enc    models/RandLA/RandLANet.py:720-727, 701-702
+//   att_pool       models/RandLA/RandLANet.py:749-752
+// and the lib/pointops signatures grouping / gathering (functions/pointops.py:61-82,151-176).
+#include "gdm_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int GB = 256;      // threads per block
+constexpr int CCHUNK = 8;    // channels per block in the gather kernels
+
+// out[b,c,e] = feat[b,c,idx[b,e]] for e in [0, m*K): covers group_gather (K>=1) and gather_nn (K==1).
+__global__ __launch_bounds__(GB) void group_gather_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                          int C, int n, long mk, float* __restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CCHUNK;
+    const long e = (long)blockIdx.x * GB + threadIdx.x;
+    if (e >= mk) return;
+    int src = idx[(long)b * mk + e];
+    src = min(max(src, 0), n - 1);
+    const int cend = min(c0 + CCHUNK, C);
+    for (int c = c0; c < cend; ++c) {
+        const long row = (long)b * C + c;
+        out[row * mk + e] = feat[row * n + src];
+    }
+}
+
+__global__ __launch_bounds__(GB) void group_gather_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
+                                                              int C, int n, long mk, float* __restrict__ gfeat)
+{
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CCHUNK;
+    const long e = (long)blockIdx.x * GB + threadIdx.x;
+    if (e >= mk) return;
+    int src = idx[(long)b * mk + e];
+    src = min(max(src, 0), n - 1);
+    const int cend = min(c0 + CCHUNK, C);
+    for (int c = c0; c < cend; ++c) {
+        const long row = (long)b * C + c;
+        atomicAdd(&gfeat[row * n + src], go[row * mk + e]);
+    }
+}
+
+// out[b,c,j] = max_k feat[b,c,idx[b,j,k]], arg = first k attaining it (torch.max semantics on CPU)
+template <int KMAX>
+__global__ __launch_bounds__(GB) void gather_max_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                        int C, int n, int m, int K, float* __restrict__ out,
+                                                        int32_t* __restrict__ arg)
+{
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CCHUNK;
+    const int j = blockIdx.x * GB + threadIdx.x;
+    if (j >= m) return;
+    int nb[KMAX];
+    const int32_t* ip = idx + ((long)b * m + j) * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int v = k < K ? ip[k] : ip[0];
+        nb[k] = min(max(v, 0), n - 1);
+    }
+    const int cend = min(c0 + CCHUNK, C);
+    for (int c = c0; c < cend; ++c) {
+        const long row = (long)b * C + c;
+        const float* f = feat + row * n;
+        float best = f[nb[0]];
+        int bi = nb[0];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
+            const float v = f[nb[k]];
+            if (v > best) {
+                best = v;
+                bi = nb[k];
+            }
+        }
+        out[row * m + j] = best;
+        if (arg) arg[row * m + j] = bi;
+    }
+}
+
+__global__ __launch_bounds__(GB) void gather_max_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ arg,
+                                                            int n, long total_rows_m, int m, float* __restrict__ gfeat)
+{
+    const long e = (long)blockIdx.x * GB + threadIdx.x;   // over [B*C, m]
+    if (e >= total_rows_m) return;
+    const long row = e / m;
+    atomicAdd(&gfeat[row * n + arg[e]], go[e]);
+}
+
+// xyz f32[B,n,3], idx i32[B,n,K] -> out f32[B,10,n,K]
+__global__ __launch_bounds__(GB) void rel_pos_enc_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx,
+                                                         int n, int K, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long nk = (long)n * K;
+    const long e = (long)blockIdx.x * GB + threadIdx.x;
+    if (e >= nk) return;
+    const int i = (int)(e / K);
+    int jn = idx[(long)b * nk + e];
+    jn = min(max(jn, 0), n - 1);
+    const float* pi = xyz + ((long)b * n + i) * 3;
+    const float* pj = xyz + ((long)b * n + jn) * 3;
+    const float ax = pi[0], ay = pi[1], az = pi[2];
+    const float bx = pj[0], by = pj[1], bz = pj[2];
+    // torch: relative = tile - neighbour; dis = sqrt(sum(relative^2)) (RandLANet.py:723-725);
+    // each square and sum rounded separately like the elementwise torch ops.
+    const float rx = __fsub_rn(ax, bx), ry = __fsub_rn(ay, by), rz = __fsub_rn(az, bz);
+    float s = __fmul_rn(rx, rx);
+    s = __fadd_rn(s, __fmul_rn(ry, ry));
+    s = __fadd_rn(s, __fmul_rn(rz, rz));
+    const float dis = __fsqrt_rn(s);
+    float* o = out + (long)b * 10 * nk + e;
+    o[0 * nk] = dis;
+    o[1 * nk] = rx; o[2 * nk] = ry; o[3 * nk] = rz;
+    o[4 * nk] = ax; o[5 * nk] = ay; o[6 * nk] = az;
+    o[7 * nk] = bx; o[8 * nk] = by; o[9 * nk] = bz;
+}
+
+// att, feat f32[rows, K] (rows = B*C*n) -> out f32[rows]: sum_k softmax_k(att) * feat
+template <int KMAX>
+__global__ __launch_bounds__(GB) void att_pool_kernel(const float* __restrict__ att, const float* __restrict__ feat,
+                                                      long rows, int K, float* __restrict__ out)
+{
+    const long r = (long)blockIdx.x * GB + threadIdx.x;
+    if (r >= rows) return;
+    const float* a = att + r * K;
+    const float* f = feat + r * K;
+    float av[KMAX], fv[KMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            av[k] = a[k];
+            fv[k] = f[k];
+            mx = fmaxf(mx, av[k]);
+        }
+    }
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            const float ex = expf(av[k] - mx);
+            den += ex;
+            av[k] = ex;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) num += fv[k] * (av[k] / den);      // feature * softmax, then summed (RandLANet.py:750-751)
+    }
+    out[r] = num;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(GB) void att_pool_bwd_kernel(const float* __restrict__ att, const float* __restrict__ feat,
+                                                          const float* __restrict__ go, long rows, int K,
+                                                          float* __restrict__ gatt, float* __restrict__ gfeat)
+{
+    const long r = (long)blockIdx.x * GB + threadIdx.x;
+    if (r >= rows) return;
+    const float* a = att + r * K;
+    const float* f = feat + r * K;
+    float sv[KMAX], fv[KMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            sv[k] = a[k];
+            fv[k] = f[k];
+            mx = fmaxf(mx, sv[k]);
+        }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            sv[k] = expf(sv[k] - mx);
+            den += sv[k];
+        }
+    }
+    float outv = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            sv[k] = sv[k] / den;
+            outv += sv[k] * fv[k];
+        }
+    }
+    const float g = go[r];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            gfeat[r * K + k] = g * sv[k];
+            gatt[r * K + k] = g * sv[k] * (fv[k] - outv);
+        }
+    }
+}
+
+// seg f32[B,2,N] -> mask u8[B,N], count i32[B]
+__global__ __launch_bounds__(GB) void seg_mask_kernel(const float* __restrict__ seg, int N, uint8_t* __restrict__ mask,
+                                                      int32_t* __restrict__ count)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * GB + threadIdx.x;
+    int sel = 0;
+    if (i < N) {
+        const float s0 = seg[((long)b * 2 + 0) * N + i];
+        const float s1 = seg[((long)b * 2 + 1) * N + i];
+        sel = s1 > s0 ? 1 : 0;                          // torch.argmax: first maximum wins on ties -> class 0
+        mask[(long)b * N + i] = (uint8_t)sel;
+    }
+    const unsigned long long bal = __ballot(sel);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&count[b], __popcll(bal));
+}
+
+} // namespace
+
+#define STREAM(s) ((hipStream_t)(s))
+
+extern "C" int gdm_group_gather_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m, int K,
+                                    float* out, void* stream)
+{
+    GDM_CHECK_ARG(feat && idx && out, "gdm_group_gather_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && C >= 1 && n >= 1 && m >= 1 && K >= 1, "gdm_group_gather_hip: bad shape B=%d C=%d n=%d m=%d K=%d", B, C, n, m, K);
+    const long mk = (long)m * K;
+    dim3 grid(gdm_cdiv(mk, GB), gdm_cdiv(C, CCHUNK), B);
+    GDM_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gdm_group_gather_hip: grid too large");
+    hipLaunchKernelGGL(group_gather_kernel, grid, dim3(GB), 0, STREAM(stream), feat, idx, C, n, mk, out);
+    return gdm_launch_status("group_gather_kernel");
+}
+
+extern "C" int gdm_group_gather_bwd_hip(const float* go, const int32_t* idx, int B, int C, int n, int m, int K,
+                                        float* gfeat, void* stream)
+{
+    GDM_CHECK_ARG(go && idx && gfeat, "gdm_group_gather_bwd_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && C >= 1 && n >= 1 && m >= 1 && K >= 1, "gdm_group_gather_bwd_hip: bad shape");
+    const long mk = (long)m * K;
+    dim3 grid(gdm_cdiv(mk, GB), gdm_cdiv(C, CCHUNK), B);
+    GDM_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gdm_group_gather_bwd_hip: grid too large");
+    hipLaunchKernelGGL(group_gather_bwd_kernel, grid, dim3(GB), 0, STREAM(stream), go, idx, C, n, mk, gfeat);
+    return gdm_launch_status("group_gather_bwd_kernel");
+}
+
+extern "C" int gdm_gather_nn_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m, float* out, void* stream)
+{
+    return gdm_group_gather_hip(feat, idx, B, C, n, m, 1, out, stream);
+}
+
+extern "C" int gdm_gather_nn_bwd_hip(const float* go, const int32_t* idx, int B, int C, int n, int m, float* gfeat, void* stream)
+{
+    return gdm_group_gather_bwd_hip(go, idx, B, C, n, m, 1, gfeat, stream);
+}
+
+extern "C" int gdm_gather_max_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m, int K,
+                                  float* out, int32_t* arg, void* stream)
+{
+    GDM_CHECK_ARG(feat && idx && out, "gdm_gather_max_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && C >= 1 && n >= 1 && m >= 1, "gdm_gather_max_hip: bad shape");
+    GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_gather_max_hip: K=%d not in [1,32]", K);
+    dim3 grid(gdm_cdiv(m, GB), gdm_cdiv(C, CCHUNK), B);
+    GDM_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gdm_gather_max_hip: grid too large");
+    if (K <= 16)
+        hipLaunchKernelGGL(gather_max_kernel<16>, grid, dim3(GB), 0, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+    else
+        hipLaunchKernelGGL(gather_max_kernel<32>, grid, dim3(GB), 0, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+    return gdm_launch_status("gather_max_kernel");
+}
+
+extern "C" int gdm_gather_max_bwd_hip(const float* go, const int32_t* arg, int B, int C, int n, int m,
+                                      float* gfeat, void* stream)
+{
+    GDM_CHECK_ARG(go && arg && gfeat, "gdm_gather_max_bwd_hip: NULL pointer");
+    const long total = (long)B * C * m;
+    hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(gdm_cdiv(total, GB)), dim3(GB), 0, STREAM(stream), go, arg, n, total, m, gfeat);
+    return gdm_launch_status("gather_max_bwd_kernel");
+}
+
+extern "C" int gdm_rel_pos_enc_hip(const float* xyz, const int32_t* idx, int B, int n, int K, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xyz && idx && out, "gdm_rel_pos_enc_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && n >= 1 && K >= 1 && B <= 65535, "gdm_rel_pos_enc_hip: bad shape");
+    dim3 grid(gdm_cdiv((long)n * K, GB), B);
+    hipLaunchKernelGGL(rel_pos_enc_kernel, grid, dim3(GB), 0, STREAM(stream), xyz, idx, n, K, out);
+    return gdm_launch_status("rel_pos_enc_kernel");
+}
+
+extern "C" int gdm_att_pool_hip(const float* att, const float* feat, int B, int C, int n, int K, float* out, void* stream)
+{
+    GDM_CHECK_ARG(att && feat && out, "gdm_att_pool_hip: NULL pointer");
+    GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_att_pool_hip: K=%d not in [1,32]", K);
+    const long rows = (long)B * C * n;
+    if (K <= 16)
+        hipLaunchKernelGGL(att_pool_kernel<16>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, rows, K, out);
+    else
+        hipLaunchKernelGGL(att_pool_kernel<32>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, rows, K, out);
+    return gdm_launch_status("att_pool_kernel");
+}
+
+extern "C" int gdm_att_pool_bwd_hip(const float* att, const float* feat, const float* go, int B, int C, int n, int K,
+                                    float* gatt, float* gfeat, void* stream)
+{
+    GDM_CHECK_ARG(att && feat && go && gatt && gfeat, "gdm_att_pool_bwd_hip: NULL pointer");
+    GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_att_pool_bwd_hip: K=%d not in [1,32]", K);
+    const long rows = (long)B * C * n;
+    if (K <= 16)
+        hipLaunchKernelGGL(att_pool_bwd_kernel<16>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, go, rows, K, gatt, gfeat);
+    else
+        hipLaunchKernelGGL(att_pool_bwd_kernel<32>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, go, rows, K, gatt, gfeat);
+    return gdm_launch_status("att_pool_bwd_kernel");
+}
+
+extern "C" int gdm_seg_mask_hip(const float* seg, int B, int N, uint8_t* mask, int32_t* count, void* stream)
+{
+    GDM_CHECK_ARG(seg && mask && count, "gdm_seg_mask_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && N >= 1 && B <= 65535, "gdm_seg_mask_hip: bad shape");
+    GDM_HIP(hipMemsetAsync(count, 0, sizeof(int32_t) * B, STREAM(stream)));
+    hipLaunchKernelGGL(seg_mask_kernel, dim3(gdm_cdiv(N, GB), B), dim3(GB), 0, STREAM(stream), seg, N, mask, count);
+    return gdm_launch_status("seg_mask_kernel");
+}

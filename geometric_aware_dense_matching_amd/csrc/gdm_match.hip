@@ -1,0 +1,367 @@
+// N x M descriptor matching for gfx950 (MI355X): cosine similarity + row arg-max, optionally
+// the materialised similarity matrix.
+//
+// Replaces (reference, /root/reference):
+//   evaluator.py:87-93    F.normalize(rows) ; F.normalize(mesh, dim=0) ; matmul ; max(dim=1)
+//   models/geoMatch.py:117-136 uses the same normalise + matmul with the (M+1)-column padded mesh
+//
+// Two kernels:
+//   1. pack_rows_kernel   [R, D=128, n] channel-major fp32  ->  R*n packed rows of 512 B:
+//        L2-normalise over D (x / max(|x|, 1e-12), F.normalize semantics) and store either
+//          BF16X3: 128 bf16 "hi" | 128 bf16 "lo"   (x = hi + lo + O(2^-18 |x|))
+//          F32   : 128 fp32
+//        Transposes through LDS so that global reads are contiguous along n and global writes
+//        are contiguous 512-B rows.
+//   2. match_kernel<PREC, WRITE_SIM>  one workgroup = 4 waves = 128 scene rows; each wave keeps
+//        its 32 rows' whole K=128 operand in registers (64 VGPRs) for the life of the kernel and
+//        streams 64-column model tiles through a double-buffered, XOR-swizzled LDS image
+//        (global -> registers before the MFMAs, registers -> LDS after them: issue-early /
+//        write-late).  Products run on the matrix cores:
+//          BF16X3: v_mfma_f32_32x32x16_bf16, three per k-step: hi*hi + hi*lo + lo*hi
+//          F32   : v_mfma_f32_32x32x2_f32 (exact fp32 products, one rounding per FMA)
+//        The epilogue keeps a running (max, first arg-max) per row in registers, reduces it
+//        across the 32 lanes of a half-wave with shuffles, and (WRITE_SIM) stores the tile.
+//        The M axis can be split over blockIdx.y; a small kernel merges the partial maxima.
+//
+// Roofline: materialised form moves 4D(BN+M) + 4BNM bytes; fused form 4D(BN+M)+8BN.
+#include "gdm_common.h"
+#include <math.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int D = 128;                 // descriptor length (config/lmo_cfg.py:125 feat_dim)
+constexpr int ROW_BYTES = 512;         // one packed row
+constexpr int MT_ROWS = 128;           // scene rows per workgroup
+constexpr int MT_COLS = 64;            // model columns per LDS tile
+constexpr int TILE_BYTES = MT_COLS * ROW_BYTES;   // 32 KiB
+
+// ------------------------------------------------------------------------------------------
+// pack: [R, 128, n] -> R*n rows
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v)
+{
+    unsigned u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);   // finite inputs only (descriptors are finite)
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int n, unsigned char* __restrict__ out)
+{
+    __shared__ float t[D][65];
+    __shared__ float part[4][64];
+    const int r = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int p = min(p0 + lane, n - 1);
+    const float* xr = x + (long)r * D * n;
+    float ss = 0.f;
+    for (int c = w; c < D; c += 4) {
+        const float v = xr[(long)c * n + p];
+        t[c][lane] = v;
+        ss += v * v;
+    }
+    part[w][lane] = ss;
+    __syncthreads();
+    // every thread recomputes the norm of the points it will write
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * 256 + threadIdx.x;       // 64 points x 16 chunks of 8 channels
+        const int ch = item & 15;
+        const int pl = item >> 4;
+        if (p0 + pl >= n) continue;
+        const float nrm = sqrtf((part[0][pl] + part[1][pl]) + (part[2][pl] + part[3][pl]));
+        const float inv_den = fmaxf(nrm, 1e-12f);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = t[ch * 8 + j][pl] / inv_den;
+        unsigned char* row = out + ((long)r * n + p0 + pl) * ROW_BYTES;
+        if (PREC == GDM_MATCH_BF16X3) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned short h0 = f32_to_bf16_rne(v[2 * j]);
+                const unsigned short h1 = f32_to_bf16_rne(v[2 * j + 1]);
+                const unsigned short l0 = f32_to_bf16_rne(v[2 * j] - bf16_to_f32(h0));
+                const unsigned short l1 = f32_to_bf16_rne(v[2 * j + 1] - bf16_to_f32(h1));
+                hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            *reinterpret_cast<uint4*>(row + ch * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(row + 256 + ch * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        } else {
+            *reinterpret_cast<float4*>(row + ch * 32) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(row + ch * 32 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// match
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_chunk_off(int col, int ch)
+{
+    // 512-B rows; XOR the low four bits of the 16-B chunk index with the column, so that the 16
+    // lanes of every ds_read_b128 group (distinct columns mod 16, same logical chunk) fall on 16
+    // different 16-B slots of the 256-B bank row.
+    return col * ROW_BYTES + (((ch & 16) | ((ch ^ col) & 15)) << 4);
+}
+
+template <int PREC, bool WRITE_SIM>
+__global__ __launch_bounds__(256) void match_kernel(const unsigned char* __restrict__ apk,   // [R] packed scene rows
+                                                    const unsigned char* __restrict__ bpk,   // [M] packed model rows
+                                                    int R, int M, int cols_per_split,
+                                                    float* __restrict__ sim,                  // [R, M] or NULL
+                                                    float* __restrict__ pval,                 // [splits, R]
+                                                    int32_t* __restrict__ pidx)               // [splits, R]
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x TILE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lr = lane & 31;        // row (A) / column (B) within a 32-block
+    const int h = lane >> 5;         // k half
+
+    const int row0 = blockIdx.x * MT_ROWS + wave * 32;
+    const int split = blockIdx.y;
+    const int col_begin = split * cols_per_split;
+    const int col_end = min(col_begin + cols_per_split, M);
+    const int ntiles = (col_end - col_begin + MT_COLS - 1) / MT_COLS;
+
+    // ---- A operand: this lane's 16 chunks, resident for the whole kernel ----
+    u32x4 areg[16];
+    {
+        const unsigned char* arow = apk + (long)min(row0 + lr, R - 1) * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int ch;
+            if (PREC == GDM_MATCH_BF16X3) ch = (i < 8) ? (2 * i + h) : (16 + 2 * (i - 8) + h);   // hi[0..7], lo[0..7]
+            else ch = 16 * h + i;                                                                // k = 64h + 4i..4i+3
+            areg[i] = *reinterpret_cast<const u32x4*>(arow + ch * 16);
+        }
+    }
+
+    float best[16];
+    int bidx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        best[i] = -INFINITY;
+        bidx[i] = 0;
+    }
+
+    // ---- tile staging: 2048 chunks per tile, 8 per thread ----
+    u32x4 stage[8];
+    auto stage_load = [&](int tile) {
+        const int c0 = col_begin + tile * MT_COLS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = i * 256 + tid;
+            const int col = g >> 5, ch = g & 31;
+            const int gc = min(c0 + col, M - 1);
+            stage[i] = *reinterpret_cast<const u32x4*>(bpk + (long)gc * ROW_BYTES + ch * 16);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = i * 256 + tid;
+            const int col = g >> 5, ch = g & 31;
+            *reinterpret_cast<u32x4*>(base + lds_chunk_off(col, ch)) = stage[i];
+        }
+    };
+
+    if (ntiles > 0) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        const bool has_next = tile + 1 < ntiles;
+        if (has_next) stage_load(tile + 1);                 // global loads in flight under the MFMAs
+
+        const unsigned char* base = smem + buf * TILE_BYTES;
+        const int tcol0 = col_begin + tile * MT_COLS;
+
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int col = cb * 32 + lr;
+            if (PREC == GDM_MATCH_BF16X3) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(base + lds_chunk_off(col, 2 * s + h));
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(base + lds_chunk_off(col, 16 + 2 * s + h));
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[s]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, areg[8 + s]);
+                    const bf16x8 vbh = __builtin_bit_cast(bf16x8, bh);
+                    const bf16x8 vbl = __builtin_bit_cast(bf16x8, bl);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vbl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vbh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vbh, acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const u32x4 bv = *reinterpret_cast<const u32x4*>(base + lds_chunk_off(col, 16 * h + i));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].x), __uint_as_float(bv.x), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].y), __uint_as_float(bv.y), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].z), __uint_as_float(bv.z), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].w), __uint_as_float(bv.w), acc, 0, 0, 0);
+                }
+            }
+            // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+            const int gcol = tcol0 + col;
+            const bool col_ok = gcol < col_end;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = acc[reg];
+                if (col_ok && v > best[reg]) {              // strict: first maximum per lane (ascending columns)
+                    best[reg] = v;
+                    bidx[reg] = gcol;
+                }
+                if (WRITE_SIM) {
+                    const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (col_ok && grow < R) sim[(long)grow * M + gcol] = v;
+                }
+            }
+        }
+
+        if (has_next) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- reduce (max, lowest arg) across the 32 lanes of each half-wave ----
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float v = best[reg];
+        int ix = bidx[reg];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float ov = __shfl_xor(v, m, 64);
+            const int oi = __shfl_xor(ix, m, 64);
+            if (ov > v || (ov == v && oi < ix)) {
+                v = ov;
+                ix = oi;
+            }
+        }
+        if (lr == 0) {
+            const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (grow < R) {
+                pval[(long)split * R + grow] = v;
+                pidx[(long)split * R + grow] = ix;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_splits_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                           int splits, int R, float* __restrict__ oval, int32_t* __restrict__ oidx)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float v = pval[r];
+    int ix = pidx[r];
+    for (int s = 1; s < splits; ++s) {               // ascending column ranges: strict '>' keeps the first maximum
+        const float ov = pval[(long)s * R + r];
+        if (ov > v) {
+            v = ov;
+            ix = pidx[(long)s * R + r];
+        }
+    }
+    oval[r] = v;
+    oidx[r] = ix;
+}
+
+int pick_splits(int R, int M, bool write_sim)
+{
+    const int row_tiles = gdm_cdiv(R, MT_ROWS);
+    const int max_splits = gdm_cdiv(M, MT_COLS);
+    int want;
+    if (write_sim) want = gdm_cdiv(M, 512);                 // ~512 columns per workgroup: thousands of workgroups
+    else want = gdm_cdiv(1024, row_tiles);                  // >= ~4 workgroups per CU when the batch is small
+    if (want < 1) want = 1;
+    if (want > max_splits) want = max_splits;
+    if (want > 64) want = 64;
+    return want;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+} // namespace
+
+extern "C" size_t gdm_match_workspace_bytes(int B, int N, int M)
+{
+    if (B < 1 || N < 1 || M < 1) return 0;
+    const size_t R = (size_t)B * N;
+    return align256(R * ROW_BYTES) + align256((size_t)M * ROW_BYTES) + 2 * align256(64 * R * sizeof(float)) + 256;
+}
+
+extern "C" int gdm_match_hip(const float* scene, const float* model, int B, int Dd, int N, int M, int precision,
+                             int32_t* best_idx, float* best_sim, float* sim,
+                             void* workspace, size_t workspace_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    GDM_CHECK_ARG(scene && model && best_idx && best_sim && workspace, "gdm_match_hip: NULL pointer");
+    GDM_CHECK_ARG(Dd == D, "gdm_match_hip: D=%d, only D=128 is built", Dd);
+    GDM_CHECK_ARG(B >= 1 && N >= 1 && M >= 1, "gdm_match_hip: bad shape B=%d N=%d M=%d", B, N, M);
+    GDM_CHECK_ARG(precision == GDM_MATCH_BF16X3 || precision == GDM_MATCH_F32, "gdm_match_hip: precision=%d", precision);
+    GDM_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "gdm_match_hip: workspace must be 16-byte aligned");
+    if (workspace_bytes < gdm_match_workspace_bytes(B, N, M)) {
+        gdm_set_error("gdm_match_hip: workspace %zu < %zu bytes", workspace_bytes, gdm_match_workspace_bytes(B, N, M));
+        return GDM_ENOMEM;
+    }
+    GDM_CHECK_ARG((long)B * N < (1L << 31) / ROW_BYTES * ROW_BYTES, "gdm_match_hip: B*N too large");
+    const int R = B * N;
+    unsigned char* ws = (unsigned char*)workspace;
+    unsigned char* apk = ws;
+    unsigned char* bpk = apk + align256((size_t)R * ROW_BYTES);
+    float* pval = (float*)(bpk + align256((size_t)M * ROW_BYTES));
+    int32_t* pidx = (int32_t*)((unsigned char*)pval + align256(64 * (size_t)R * sizeof(float)));
+
+    dim3 pg_s(gdm_cdiv(N, 64), B), pg_m(gdm_cdiv(M, 64), 1);
+    GDM_CHECK_ARG(B <= 65535, "gdm_match_hip: B too large");
+    if (precision == GDM_MATCH_BF16X3) {
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_BF16X3>, pg_s, dim3(256), 0, stream, scene, N, apk);
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_BF16X3>, pg_m, dim3(256), 0, stream, model, M, bpk);
+    } else {
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_F32>, pg_s, dim3(256), 0, stream, scene, N, apk);
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_F32>, pg_m, dim3(256), 0, stream, model, M, bpk);
+    }
+    int rc = gdm_launch_status("pack_rows_kernel");
+    if (rc) return rc;
+
+    const bool ws_sim = sim != nullptr;
+    const int splits = pick_splits(R, M, ws_sim);
+    int cps = gdm_cdiv(gdm_cdiv(M, splits), MT_COLS) * MT_COLS;
+    const int nsplit = gdm_cdiv(M, cps);
+    dim3 grid(gdm_cdiv(R, MT_ROWS), nsplit);
+    float* ov = nsplit == 1 ? best_sim : pval;
+    int32_t* oi = nsplit == 1 ? best_idx : pidx;
+    const size_t lds = 2 * TILE_BYTES;
+#define LAUNCH(P, W) hipLaunchKernelGGL((match_kernel<P, W>), grid, dim3(256), lds, stream, apk, bpk, R, M, cps, sim, ov, oi)
+    if (precision == GDM_MATCH_BF16X3) {
+        if (ws_sim) LAUNCH(GDM_MATCH_BF16X3, true); else LAUNCH(GDM_MATCH_BF16X3, false);
+    } else {
+        if (ws_sim) LAUNCH(GDM_MATCH_F32, true); else LAUNCH(GDM_MATCH_F32, false);
+    }
+#undef LAUNCH
+    rc = gdm_launch_status("match_kernel");
+    if (rc) return rc;
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(merge_splits_kernel, dim3(gdm_cdiv(R, 256)), dim3(256), 0, stream, pval, pidx, nsplit, R, best_sim, best_idx);
+        rc = gdm_launch_status("merge_splits_kernel");
+    }
+    return rc;
+}

@@ -1,0 +1,294 @@
+"""Torch-facing operators over the C ABI of libgdm_hip.so.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every operator
+passes raw device pointers + that stream to the hand-written HIP kernels.  There is no CPU
+path: CPU tensors raise.  Index tensors are int32 on the device (the reference widens them to
+int64 only because torch.gather demands it: /root/reference/train_lm.py:167-168); int64 is
+accepted and narrowed.
+
+Operator <-> reference map (file:line under /root/reference):
+  knn_batch / knn_jobs   models/RandLA/utils/nearest_neighbors/knn.pyx:71-109, knn_.cxx:104-135
+  group_gather           models/RandLA/RandLANet.py:729-738 (+ permute :704-716); pointops.py:151-176
+  gather_max             models/ffb6d.py:128-146 random_sample
+  gather_nn              models/ffb6d.py:148-163 nearest_interpolation; pointops.py:61-82
+  rel_pos_enc            models/RandLA/RandLANet.py:720-727
+  att_pool               models/RandLA/RandLANet.py:749-752
+  match / seg_mask       evaluator.py:79-93
+  ballquery / furthestsampling   lib/pointops/functions/pointops.py:205-219, 40-50
+"""
+import torch
+
+from . import _lib
+from ._lib import KnnJob, check
+
+MATCH_BF16X3 = 0
+MATCH_F32 = 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor: the geoMatch ops have no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _idx32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor: the geoMatch ops have no CPU fallback" % name)
+    if t.dtype == torch.int64:
+        t = t.to(torch.int32)
+    elif t.dtype != torch.int32:
+        raise TypeError("%s must be int32 or int64, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# neighbour search
+# --------------------------------------------------------------------------------------
+def knn_batch(support, query, K, return_d2=False):
+    """support f32[B,S,3], query f32[B,Q,3] -> idx i32[B,Q,K] (ascending d2, ties by index)."""
+    support = _dev(support, torch.float32, "support")
+    query = _dev(query, torch.float32, "query")
+    B, S, _ = support.shape
+    Q = query.shape[1]
+    assert support.shape[2] == 3 and query.shape[2] == 3 and query.shape[0] == B
+    idx = torch.empty((B, Q, K), dtype=torch.int32, device=support.device)
+    d2 = torch.empty((B, Q, K), dtype=torch.float32, device=support.device) if return_d2 else None
+    check(_lib.lib().gdm_knn_batch_hip(support.data_ptr(), query.data_ptr(), B, S, Q, K, idx.data_ptr(),
+                                       d2.data_ptr() if return_d2 else None, _stream()), "gdm_knn_batch_hip")
+    return (idx, d2) if return_d2 else idx
+
+
+def knn_jobs(jobs, B):
+    """jobs: list of (support f32 view [B,S,3], query f32 view [B,Q,3], K).  Views may be prefix
+    slices along dim 1 of contiguous [B,N,3] arrays (batch stride kept).  One launch per K class.
+    Returns the list of idx tensors i32[B,Q,K]."""
+    n = len(jobs)
+    arr = (KnnJob * n)()
+    outs = []
+    keep = []
+    for i, (sup, qry, K) in enumerate(jobs):
+        for t, nm in ((sup, "support"), (qry, "query")):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("knn_jobs: %s must be a CUDA float32 tensor" % nm)
+            if t.dim() != 3 or t.shape[0] != B or t.shape[2] != 3 or t.stride(2) != 1 or t.stride(1) != 3:
+                raise ValueError("knn_jobs: %s must be [B,n,3] with unit point stride, got %s strides %s" %
+                                 (nm, tuple(t.shape), t.stride()))
+        S, Q = sup.shape[1], qry.shape[1]
+        out = torch.empty((B, Q, K), dtype=torch.int32, device=sup.device)
+        arr[i].support = sup.data_ptr()
+        arr[i].query = qry.data_ptr()
+        arr[i].idx = out.data_ptr()
+        arr[i].d2 = None
+        arr[i].support_bstride = sup.stride(0) if B > 1 else S * 3
+        arr[i].query_bstride = qry.stride(0) if B > 1 else Q * 3
+        arr[i].S, arr[i].Q, arr[i].K = S, Q, K
+        outs.append(out)
+        keep.append((sup, qry))
+    check(_lib.lib().gdm_knn_jobs_hip(arr, n, B, _stream()), "gdm_knn_jobs_hip")
+    return outs
+
+
+def ballquery(radius, nsample, xyz, new_xyz):
+    """pointops.BallQuery.forward argument order (pointops.py:205): -> i32[B,m,nsample]."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    new_xyz = _dev(new_xyz, torch.float32, "new_xyz")
+    B, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.zeros((B, m, nsample), dtype=torch.int32, device=xyz.device)
+    check(_lib.lib().gdm_ballquery_hip(B, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+                                       idx.data_ptr(), _stream()), "gdm_ballquery_hip")
+    return idx
+
+
+def furthestsampling(xyz, m):
+    """pointops.FurthestSampling.forward (pointops.py:40-50): xyz f32[B,n,3] -> i32[B,m]."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    B, n, _ = xyz.shape
+    idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
+    temp = torch.empty((B, n), dtype=torch.float32, device=xyz.device)
+    check(_lib.lib().gdm_furthestsampling_hip(B, n, m, xyz.data_ptr(), temp.data_ptr(), idx.data_ptr(), _stream()),
+          "gdm_furthestsampling_hip")
+    return idx
+
+
+# --------------------------------------------------------------------------------------
+# gather / pool, with backward
+# --------------------------------------------------------------------------------------
+def _feat3(feat):
+    if feat.dim() == 4:
+        assert feat.shape[3] == 1
+        feat = feat.squeeze(3)
+    return feat
+
+
+class _GroupGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        feat = _dev(feat, torch.float32, "feat")
+        B, C, n = feat.shape
+        m, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, C, m, K), dtype=torch.float32, device=feat.device)
+        check(_lib.lib().gdm_group_gather_hip(feat.data_ptr(), idx.data_ptr(), B, C, n, m, K, out.data_ptr(), _stream()),
+              "gdm_group_gather_hip")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (idx,) = ctx.saved_tensors
+        go = go.contiguous()
+        B, C, m, K = go.shape
+        g = torch.zeros((B, C, ctx.n), dtype=torch.float32, device=go.device)
+        check(_lib.lib().gdm_group_gather_bwd_hip(go.data_ptr(), idx.data_ptr(), B, C, ctx.n, m, K, g.data_ptr(), _stream()),
+              "gdm_group_gather_bwd_hip")
+        return g, None
+
+
+def group_gather(feat, idx):
+    """feat f32[B,C,n(,1)], idx int[B,m,K] -> f32[B,C,m,K]."""
+    idx = _idx32(idx, "idx")
+    assert idx.dim() == 3
+    return _GroupGather.apply(_feat3(feat), idx)
+
+
+def gather_nn(feat, idx):
+    """feat f32[B,C,n(,1)], idx int[B,m] or [B,m,1] -> f32[B,C,m]."""
+    idx = _idx32(idx, "idx")
+    if idx.dim() == 2:
+        idx = idx.unsqueeze(2)
+    assert idx.shape[2] == 1
+    return _GroupGather.apply(_feat3(feat), idx).squeeze(3)
+
+
+class _GatherMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        feat = _dev(feat, torch.float32, "feat")
+        B, C, n = feat.shape
+        m, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, C, m), dtype=torch.float32, device=feat.device)
+        need_arg = feat.requires_grad
+        arg = torch.empty((B, C, m), dtype=torch.int32, device=feat.device) if need_arg else None
+        check(_lib.lib().gdm_gather_max_hip(feat.data_ptr(), idx.data_ptr(), B, C, n, m, K, out.data_ptr(),
+                                            arg.data_ptr() if need_arg else None, _stream()), "gdm_gather_max_hip")
+        if need_arg:
+            ctx.save_for_backward(arg)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (arg,) = ctx.saved_tensors
+        go = go.contiguous()
+        B, C, m = go.shape
+        g = torch.zeros((B, C, ctx.n), dtype=torch.float32, device=go.device)
+        check(_lib.lib().gdm_gather_max_bwd_hip(go.data_ptr(), arg.data_ptr(), B, C, ctx.n, m, g.data_ptr(), _stream()),
+              "gdm_gather_max_bwd_hip")
+        return g, None
+
+
+def gather_max(feat, idx):
+    """feat f32[B,C,n(,1)], idx int[B,m,K] -> f32[B,C,m] = max over the K gathered neighbours."""
+    idx = _idx32(idx, "idx")
+    assert idx.dim() == 3
+    return _GatherMax.apply(_feat3(feat), idx)
+
+
+def rel_pos_enc(xyz, idx):
+    """xyz f32[B,n,3], idx int[B,n,K] -> f32[B,10,n,K] (inputs are data: no gradient)."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    idx = _idx32(idx, "idx")
+    B, n, _ = xyz.shape
+    K = idx.shape[2]
+    assert idx.shape[0] == B and idx.shape[1] == n
+    out = torch.empty((B, 10, n, K), dtype=torch.float32, device=xyz.device)
+    check(_lib.lib().gdm_rel_pos_enc_hip(xyz.data_ptr(), idx.data_ptr(), B, n, K, out.data_ptr(), _stream()),
+          "gdm_rel_pos_enc_hip")
+    return out
+
+
+class _AttPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, feat):
+        att = _dev(att, torch.float32, "att")
+        feat = _dev(feat, torch.float32, "feat")
+        B, C, n, K = att.shape
+        assert feat.shape == att.shape
+        out = torch.empty((B, C, n), dtype=torch.float32, device=att.device)
+        check(_lib.lib().gdm_att_pool_hip(att.data_ptr(), feat.data_ptr(), B, C, n, K, out.data_ptr(), _stream()),
+              "gdm_att_pool_hip")
+        ctx.save_for_backward(att, feat)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        att, feat = ctx.saved_tensors
+        go = go.contiguous()
+        B, C, n, K = att.shape
+        ga = torch.empty_like(att)
+        gf = torch.empty_like(feat)
+        check(_lib.lib().gdm_att_pool_bwd_hip(att.data_ptr(), feat.data_ptr(), go.data_ptr(), B, C, n, K,
+                                              ga.data_ptr(), gf.data_ptr(), _stream()), "gdm_att_pool_bwd_hip")
+        return ga, gf
+
+
+def att_pool(att, feat):
+    """att, feat f32[B,C,n,K] -> f32[B,C,n]: sum_k softmax_k(att) * feat."""
+    return _AttPool.apply(att, feat)
+
+
+# --------------------------------------------------------------------------------------
+# matching
+# --------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def match(scene, model, precision=MATCH_BF16X3, return_sim=False):
+    """scene f32[B,128,N] (end_points['rgbd']), model f32[128,M] (end_points['mesh'][0]).
+    Returns best_idx i32[B,N], best_sim f32[B,N] (and sim f32[B,N,M] when return_sim)."""
+    scene = _dev(scene, torch.float32, "scene")
+    model = _dev(model, torch.float32, "model")
+    if model.dim() == 3:
+        assert model.shape[0] == 1
+        model = model[0]
+    B, D, N = scene.shape
+    M = model.shape[1]
+    assert model.shape[0] == D
+    L = _lib.lib()
+    nbytes = L.gdm_match_workspace_bytes(B, N, M)
+    ws = _workspace(nbytes, scene.device)
+    best_idx = torch.empty((B, N), dtype=torch.int32, device=scene.device)
+    best_sim = torch.empty((B, N), dtype=torch.float32, device=scene.device)
+    sim = torch.empty((B, N, M), dtype=torch.float32, device=scene.device) if return_sim else None
+    check(L.gdm_match_hip(scene.data_ptr(), model.data_ptr(), B, D, N, M, precision, best_idx.data_ptr(),
+                          best_sim.data_ptr(), sim.data_ptr() if return_sim else None, ws.data_ptr(), ws.numel(),
+                          _stream()), "gdm_match_hip")
+    return (best_idx, best_sim, sim) if return_sim else (best_idx, best_sim)
+
+
+def seg_mask(seg):
+    """seg f32[B,2,N] -> (mask u8[B,N] = argmax==1, count i32[B])."""
+    seg = _dev(seg, torch.float32, "seg")
+    B, two, N = seg.shape
+    assert two == 2
+    mask = torch.empty((B, N), dtype=torch.uint8, device=seg.device)
+    count = torch.empty((B,), dtype=torch.int32, device=seg.device)
+    check(_lib.lib().gdm_seg_mask_hip(seg.data_ptr(), B, N, mask.data_ptr(), count.data_ptr(), _stream()),
+          "gdm_seg_mask_hip")
+    return mask, count

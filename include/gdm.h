@@ -1,0 +1,148 @@
+/*
+ * gdm.h -- C ABI of libgdm_hip.so, the MI355X (gfx950) implementation of the geoMatch
+ * dense-correspondence hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every `*_hip` entry point takes DEVICE pointers and a HIP stream (hipStream_t passed
+ *     as void*; NULL = the null stream), enqueues its kernels on that stream and returns
+ *     without synchronising.  All are re-entrant (no global mutable state), so they can be
+ *     driven from several host threads on several streams, as evaluator.py:294-303 does.
+ *   - return value: 0 on success, a positive hipError_t, or a negative GDM_E* code.
+ *     gdm_last_error() returns a thread-local description of the last failure.
+ *   - all tensors are dense, row-major, fp32 unless said otherwise; indices are int32.
+ *   - the reference interface each entry point replaces is cited as file:line under
+ *     /root/reference.
+ */
+#ifndef GDM_H
+#define GDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDM_EINVAL (-1)   /* bad argument (shape, K, alignment) */
+#define GDM_ENOMEM (-2)   /* workspace too small */
+
+const char* gdm_last_error(void);
+/* ABI version, bumped when a signature changes. */
+int gdm_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Exact K-nearest-neighbour search (fp32 squared L2, ascending; ties by ascending index).
+ * ------------------------------------------------------------------------------------- */
+
+/* Drop-in for the reference's only native entry point on the live path:
+ *   void cpp_knn_batch_omp(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+ *                          const float* queries, size_t nqueries, size_t K, long* batch_indices)
+ *   models/RandLA/utils/nearest_neighbors/knn_.h:17-19, knn_.cxx:104-135
+ * Same argument list, HOST pointers, caller-allocated output, no return code (as the
+ * reference).  Runs on the GPU: H2D copy, gdm_knn_batch_hip, D2H copy, widened to long.
+ * dim must be 3.  On failure indices are left untouched and gdm_last_error() is set.   */
+void gdm_knn_batch(const float* batch_data, size_t batch_size, size_t npts, size_t dim,
+                   const float* queries, size_t nqueries, size_t K, long* batch_indices);
+
+/* Device-resident form. support f32[B,S,3], query f32[B,Q,3] -> idx i32[B,Q,K],
+ * d2 f32[B,Q,K] (may be NULL).  1 <= K <= 32.  Slots beyond S (K > S) hold index 0, as the
+ * zero-initialised output of knn.pyx:93 does.                                           */
+int gdm_knn_batch_hip(const float* support, const float* query, int B, int S, int Q, int K,
+                      int32_t* idx, float* d2, void* stream);
+
+/* One launch for a whole table of independent searches (the 22 calls per crop of
+ * datasets/lm/linemod_pbr.py:534-569, for all crops of a batch).                        */
+typedef struct gdm_knn_job {
+    const float* support;     /* f32[B,S,3], batch item b at support + b*support_bstride */
+    const float* query;       /* f32[B,Q,3], batch item b at query + b*query_bstride     */
+    int32_t* idx;             /* i32[B,Q,K] dense */
+    float* d2;                /* f32[B,Q,K] dense, or NULL */
+    int64_t support_bstride;  /* in floats; S*3 when dense. A prefix slice cld[:, :S] of a  */
+    int64_t query_bstride;    /* [B,N,3] array keeps bstride N*3 (linemod_pbr.py:538)     */
+    int32_t S, Q, K, _pad;
+} gdm_knn_job;
+#define GDM_KNN_MAX_JOBS 32
+int gdm_knn_jobs_hip(const gdm_knn_job* jobs /* host array */, int njobs, int B, void* stream);
+
+/* Ball query (lib/pointops/functions/pointops.py:205-219 `ballquery_cuda(b,n,m,radius,nsample,
+ * new_xyz,xyz,idx)`): for each centre the first `nsample` support indices (ascending index)
+ * with d2 < radius^2; remaining slots repeat the first hit; all zero when none.
+ * xyz f32[B,n,3], new_xyz f32[B,m,3] -> idx i32[B,m,nsample].                           */
+int gdm_ballquery_hip(int B, int n, int m, float radius, int nsample,
+                      const float* new_xyz, const float* xyz, int32_t* idx, void* stream);
+
+/* Furthest point sampling (pointops.py:40-50 `furthestsampling_cuda(b,n,m,xyz,temp,idx)`):
+ * starts from index 0, `temp` f32[B,n] is scratch (initialised inside).                  */
+int gdm_furthestsampling_hip(int B, int n, int m, const float* xyz, float* temp, int32_t* idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Feature gather / scatter (channel-major features, as the reference network keeps them).
+ * ------------------------------------------------------------------------------------- */
+
+/* out[b,c,j,k] = feat[b,c,idx[b,j,k]]   feat f32[B,C,n], idx i32[B,m,K] -> f32[B,C,m,K]
+ * replaces Building_block.gather_neighbour + permute (models/RandLA/RandLANet.py:729-738,
+ * 704-716) and pointops grouping_forward_cuda (pointops.py:151-176).                     */
+int gdm_group_gather_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m, int K,
+                         float* out, void* stream);
+/* grad_feat[b,c,idx[b,j,k]] += grad_out[b,c,j,k]; grad_feat must be zeroed by the caller. */
+int gdm_group_gather_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int m, int K,
+                             float* grad_feat, void* stream);
+
+/* out[b,c,j] = max_k feat[b,c,idx[b,j,k]]; arg i32[B,C,m] (may be NULL) = winning source index.
+ * replaces FFB6DEmb.random_sample (models/ffb6d.py:128-146).                             */
+int gdm_gather_max_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m, int K,
+                       float* out, int32_t* arg, void* stream);
+/* grad_feat[b,c,arg[b,c,j]] += grad_out[b,c,j]; grad_feat zeroed by the caller.          */
+int gdm_gather_max_bwd_hip(const float* grad_out, const int32_t* arg, int B, int C, int n, int m,
+                           float* grad_feat, void* stream);
+
+/* out[b,c,j] = feat[b,c,idx[b,j]]      (K == 1)
+ * replaces FFB6DEmb.nearest_interpolation (models/ffb6d.py:148-163), the `choose` gather
+ * (ffb6d.py:278-281) and pointops gathering_forward_cuda (pointops.py:61-82).
+ * idx_bstride = elements between batch items of idx (0 broadcasts one index row).        */
+int gdm_gather_nn_hip(const float* feat, const int32_t* idx, int B, int C, int n, int m,
+                      float* out, void* stream);
+int gdm_gather_nn_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int m,
+                          float* grad_feat, void* stream);
+
+/* Relative position encoding (RandLANet.py:720-727 + the permute of :701-702):
+ * xyz f32[B,n,3], idx i32[B,n,K] -> out f32[B,10,n,K] with channels
+ * [ |p_i-p_j|, p_i-p_j (3), p_i (3), p_j (3) ].                                          */
+int gdm_rel_pos_enc_hip(const float* xyz, const int32_t* idx, int B, int n, int K, float* out, void* stream);
+
+/* Attentive pooling core (RandLANet.py:749-752): softmax of `att` over K, weighted sum of
+ * `feat` over K.  att, feat f32[B,C,n,K] -> out f32[B,C,n].                              */
+int gdm_att_pool_hip(const float* att, const float* feat, int B, int C, int n, int K, float* out, void* stream);
+int gdm_att_pool_bwd_hip(const float* att, const float* feat, const float* grad_out, int B, int C, int n, int K,
+                         float* grad_att, float* grad_feat, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * N x M descriptor matching (cosine similarity + row arg-max).
+ * ------------------------------------------------------------------------------------- */
+
+#define GDM_MATCH_BF16X3 0   /* split-bf16 MFMA: hi*hi + hi*lo + lo*hi, fp32 accumulate (|err| <= ~1.2e-5) */
+#define GDM_MATCH_F32    1   /* f32-input MFMA, exact fp32 products                                        */
+
+/* Workspace bytes needed by gdm_match_*_hip for the given sizes. */
+size_t gdm_match_workspace_bytes(int B, int N, int M);
+
+/* Fused inference matching (evaluator.py:87-93): L2-normalise each scene descriptor (over D),
+ * each model descriptor (over D), similarity = scene . model, per scene point the maximum
+ * over the M model vertices and its index (first maximum on exact ties).
+ *   scene f32[B,D,N] channel-major (GeoMatch end_points['rgbd'], geoMatch.py:199)
+ *   model f32[D,M]   channel-major (end_points['mesh'][0])
+ *   -> best_idx i32[B,N], best_sim f32[B,N]; sim f32[B,N,M] is also written when non-NULL
+ *      (the materialised matrix of evaluator.py:91).
+ * D must be 128; N % 32 == 0... (see gdm_match.hip); M % 64 == 0.                          */
+int gdm_match_hip(const float* scene, const float* model, int B, int D, int N, int M, int precision,
+                  int32_t* best_idx, float* best_sim, float* sim,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* seg f32[B,2,N] -> mask u8[B,N] = (argmax over the 2 classes == 1) (evaluator.py:79-83),
+ * count i32[B] of selected points (zeroed inside).                                        */
+int gdm_seg_mask_hip(const float* seg, int B, int N, uint8_t* mask, int32_t* count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDM_H */

@@ -1,0 +1,252 @@
+"""GPU parity tests of the HIP operators against the oracle (tests call through the C ABI via
+geometric_aware_dense_matching_amd.ops).  Bit-exact for indices and pure data movement; fp32
+tolerances are written at each check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from geometric_aware_dense_matching_amd import ops as o
+    return o
+
+
+def _cloud(rs, B, n):
+    return rs.rand(B, n, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("S,Q,K", [(2048, 2048, 16), (512, 2048, 1), (4096, 512, 16), (512, 4096, 1),
+                                    (32, 32, 16), (8, 32, 1), (1024, 8, 16), (8, 1024, 1),
+                                    (16384, 128, 16), (128, 16384, 1), (1000, 77, 5), (300, 3, 20), (4, 9, 16)])
+def test_knn_matches_oracle_bit_exact(ops, S, Q, K):
+    from oracle import knn as oknn
+    rs = np.random.RandomState(S * 7 + Q)
+    B = 2
+    sup, qry = _cloud(rs, B, S), _cloud(rs, B, Q)
+    want, want_d2 = oknn.knn_batch(sup, qry, K, return_d2=True)
+    got, got_d2 = ops.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), K, return_d2=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+    assert np.array_equal(got_d2.cpu().numpy(), want_d2)          # same fp32 arithmetic, no FMA
+
+
+def test_knn_duplicates_canonical_order(ops):
+    """Duplicate points (the loader's np.pad 'wrap'): ties resolved by ascending index, as the oracle."""
+    from oracle import knn as oknn
+    rs = np.random.RandomState(3)
+    base = _cloud(rs, 1, 700)
+    sup = np.concatenate([base, base[:, :324]], axis=1)
+    want, want_d2 = oknn.knn_batch(sup, sup, 16, return_d2=True)
+    got, got_d2 = ops.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(sup).cuda(), 16, return_d2=True)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+    assert np.array_equal(got_d2.cpu().numpy(), want_d2)
+
+
+def test_knn_reference_parity_tie_free(ops):
+    """Against the REAL reference (nanoflann, oracle/_ref) when its build travelled with the snapshot."""
+    from oracle import knn as oknn
+    if not oknn.have_ref():
+        pytest.skip("oracle/_ref/libknn_ref.so not present")
+    rs = np.random.RandomState(11)
+    sup, qry = _cloud(rs, 1, 2048), _cloud(rs, 1, 512)
+    want = oknn.ref_knn_batch(sup, qry, 16)
+    got = ops.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 16)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+
+
+def test_knn_host_dropin_signature(ops):
+    """gdm_knn_batch: host pointers, exact cpp_knn_batch_omp argument list (knn_.h:17-19)."""
+    import ctypes
+    from geometric_aware_dense_matching_amd import _lib
+    from oracle import knn as oknn
+    rs = np.random.RandomState(5)
+    sup, qry = _cloud(rs, 3, 500), _cloud(rs, 3, 200)
+    out = np.zeros((3, 200, 16), dtype=np.int64)
+    _lib.lib().gdm_knn_batch(sup.ctypes.data, 3, 500, 3, qry.ctypes.data, 200, 16, out.ctypes.data)
+    assert np.array_equal(out, oknn.knn_batch(sup, qry, 16))
+
+
+def test_knn_jobs_prefix_views(ops):
+    from oracle import knn as oknn
+    rs = np.random.RandomState(9)
+    B = 3
+    cld = torch.from_numpy(_cloud(rs, B, 1024)).cuda()
+    px = torch.from_numpy(_cloud(rs, B, 4096)).cuda()
+    sub = cld[:, :256]
+    outs = ops.knn_jobs([(cld, cld, 16), (sub, cld, 1), (px, sub, 16), (sub, px, 1)], B)
+    c, s, p = cld.cpu().numpy(), sub.cpu().numpy(), px.cpu().numpy()
+    for got, (a, b, k) in zip(outs, [(c, c, 16), (s, c, 1), (p, s, 16), (s, p, 1)]):
+        assert np.array_equal(got.cpu().numpy().astype(np.int64), oknn.knn_batch(a, b, k))
+
+
+def _feat_idx(rs, B, C, n, m, K):
+    feat = torch.from_numpy(rs.randn(B, C, n).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, n, size=(B, m, K)).astype(np.int64))
+    return feat, idx
+
+
+@pytest.mark.parametrize("B,C,n,m,K", [(2, 64, 2048, 512, 16), (1, 3, 100, 37, 5), (2, 129, 300, 300, 16), (2, 64, 4096, 128, 16)])
+def test_gather_max(ops, B, C, n, m, K):
+    from oracle import ops_ref
+    feat, idx = _feat_idx(np.random.RandomState(1), B, C, n, m, K)
+    want = ops_ref.random_sample(feat.unsqueeze(3), idx).squeeze(3)
+    got = ops.gather_max(feat.cuda(), idx.cuda())
+    assert torch.equal(got.cpu(), want)                             # pure selection: bit-exact
+
+
+@pytest.mark.parametrize("B,C,n,m", [(2, 64, 512, 16384), (1, 7, 33, 100), (2, 256, 32, 1024)])
+def test_gather_nn(ops, B, C, n, m):
+    from oracle import ops_ref
+    feat, idx = _feat_idx(np.random.RandomState(2), B, C, n, m, 1)
+    want = ops_ref.nearest_interpolation(feat.unsqueeze(3), idx).squeeze(3)
+    got = ops.gather_nn(feat.cuda(), idx.cuda())
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("B,C,n,K", [(2, 16, 2048, 16), (1, 5, 50, 3), (2, 128, 32, 16)])
+def test_group_gather(ops, B, C, n, K):
+    from oracle import ops_ref
+    feat, idx = _feat_idx(np.random.RandomState(3), B, C, n, n, K)
+    want = ops_ref.group_gather(feat, idx)
+    got = ops.group_gather(feat.cuda(), idx.cuda())
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("B,n,K", [(2, 2048, 16), (1, 40, 16), (3, 128, 4)])
+def test_rel_pos_enc(ops, B, n, K):
+    from oracle import ops_ref
+    rs = np.random.RandomState(4)
+    xyz = torch.from_numpy(rs.rand(B, n, 3).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, n, size=(B, n, K)).astype(np.int64))
+    want = ops_ref.relative_pos_encoding(xyz, idx)
+    got = ops.rel_pos_enc(xyz.cuda(), idx.cuda()).cpu()
+    # channels 1..9 are copies / single subtractions: bit-exact. channel 0 = sqrt of a 3-term sum whose
+    # association order inside torch.sum is not specified: 2 ulp.
+    assert torch.equal(got[:, 1:], want[:, 1:])
+    assert torch.allclose(got[:, 0], want[:, 0], rtol=3e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("B,C,n,K", [(2, 32, 2048, 16), (1, 5, 77, 16), (2, 256, 32, 16), (1, 8, 64, 5)])
+def test_att_pool(ops, B, C, n, K):
+    from oracle import ops_ref
+    rs = np.random.RandomState(5)
+    att = torch.from_numpy(rs.randn(B, C, n, K).astype(np.float32) * 3)
+    feat = torch.from_numpy(rs.randn(B, C, n, K).astype(np.float32))
+    want = ops_ref.att_pool_core(att, feat).squeeze(3)
+    got = ops.att_pool(att.cuda(), feat.cuda()).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)          # exp / summation order
+
+
+def test_gather_backward_matches_autograd(ops):
+    from oracle import ops_ref
+    rs = np.random.RandomState(6)
+    B, C, n, m, K = 2, 24, 200, 150, 16
+    feat, idx = _feat_idx(rs, B, C, n, m, K)
+    for ref_fn, fn in ((lambda f: ops_ref.random_sample(f.unsqueeze(3), idx).squeeze(3), lambda f: ops.gather_max(f, idx.cuda())),
+                       (lambda f: ops_ref.group_gather(f, idx), lambda f: ops.group_gather(f, idx.cuda())),
+                       (lambda f: ops_ref.nearest_interpolation(f.unsqueeze(3), idx[:, :, :1]).squeeze(3),
+                        lambda f: ops.gather_nn(f, idx[:, :, :1].cuda()))):
+        a = feat.clone().requires_grad_(True)
+        ya = ref_fn(a)
+        w = torch.from_numpy(rs.randn(*ya.shape).astype(np.float32))
+        (ya * w).sum().backward()
+        b = feat.clone().cuda().requires_grad_(True)
+        yb = fn(b)
+        (yb * w.cuda()).sum().backward()
+        assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-5, atol=1e-5)   # atomic add order
+    att = torch.from_numpy(rs.randn(2, 8, 50, 16).astype(np.float32))
+    f = torch.from_numpy(rs.randn(2, 8, 50, 16).astype(np.float32))
+    a1, f1 = att.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    y = ops_ref.att_pool_core(a1, f1).squeeze(3)
+    w = torch.from_numpy(rs.randn(*y.shape).astype(np.float32))
+    (y * w).sum().backward()
+    a2, f2 = att.clone().cuda().requires_grad_(True), f.clone().cuda().requires_grad_(True)
+    (ops.att_pool(a2, f2) * w.cuda()).sum().backward()
+    assert torch.allclose(a2.grad.cpu(), a1.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(f2.grad.cpu(), f1.grad, rtol=1e-4, atol=1e-6)
+
+
+def _desc(rs, B, N, M):
+    scene = torch.from_numpy(rs.randn(B, 128, N).astype(np.float32) * rs.rand(B, 1, N).astype(np.float32) * 3)
+    model = torch.from_numpy(rs.randn(128, M).astype(np.float32))
+    return scene, model
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,N,M", [(1, 1024, 4096), (2, 2048, 8192), (1, 200, 333), (3, 128, 8193)])
+def test_match_vs_oracle(ops, prec, B, N, M):
+    """north_star: fp32 similarities within 1e-4 of the reference CPU path. Arg-max: identical index, or a
+    different index whose oracle similarity is within the same tolerance of the oracle maximum (near-tie)."""
+    from oracle import ops_ref
+    scene, model = _desc(np.random.RandomState(N + M), B, N, M)
+    gi, gv, gs = ops.match(scene.cuda(), model.cuda(), precision=prec, return_sim=True)
+    gi2, gv2 = ops.match(scene.cuda(), model.cuda(), precision=prec)
+    gi, gv, gs, gi2, gv2 = gi.cpu(), gv.cpu(), gs.cpu(), gi2.cpu(), gv2.cpu()
+    tol = 1e-4
+    for b in range(B):
+        wv, wi, ws = ops_ref.match_argmax(scene[b], model)
+        assert (gs[b] - ws).abs().max().item() < tol
+        assert (gv[b] - wv).abs().max().item() < tol
+        at_got = ws.gather(1, gi[b].long().unsqueeze(1)).squeeze(1)
+        assert ((wv - at_got) < tol).all()
+        assert (gi[b].long() == wi).float().mean().item() > 0.999
+    # fused (no matrix) and materialising launches agree exactly with each other
+    assert torch.equal(gv, gv2) and torch.equal(gi, gi2)
+    # and the materialised matrix is consistent with the reported maxima
+    assert torch.equal(gs.max(dim=2)[0], gv)
+
+
+def test_match_first_max_on_exact_ties(ops):
+    """Duplicate model vertices give exactly equal similarities: the lowest index must win (torch.max CPU)."""
+    rs = np.random.RandomState(0)
+    scene, model = _desc(rs, 1, 256, 512)
+    model[:, 300:] = model[:, :212]
+    gi, gv = ops.match(scene.cuda(), model.cuda(), precision=1)
+    assert (gi.cpu() < 300).all()
+
+
+def test_seg_mask(ops):
+    from oracle import ops_ref
+    rs = np.random.RandomState(1)
+    seg = torch.from_numpy(rs.randn(3, 2, 1000).astype(np.float32))
+    seg[0, 1, :10] = seg[0, 0, :10]            # exact ties -> class 0
+    mask, count = ops.seg_mask(seg.cuda())
+    for b in range(3):
+        want = ops_ref.seg_mask(seg[b])
+        assert torch.equal(mask[b].cpu().bool(), want)
+        assert count[b].item() == int(want.sum())
+
+
+def test_pointops_ballquery_fps(ops):
+    rs = np.random.RandomState(2)
+    xyz = rs.rand(2, 500, 3).astype(np.float32)
+    new = xyz[:, :64].copy()
+    r, ns = 0.2, 8
+    got = ops.ballquery(r, ns, torch.from_numpy(xyz).cuda(), torch.from_numpy(new).cuda()).cpu().numpy()
+    for b in range(2):
+        d = xyz[b][None, :, :] - new[b][:, None, :]
+        d2 = ((d[..., 0] * d[..., 0]) + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        for j in range(64):
+            hits = np.nonzero(d2[j] < np.float32(r) * np.float32(r))[0][:ns]
+            want = np.full(ns, hits[0] if len(hits) else 0)
+            want[:len(hits)] = hits
+            assert np.array_equal(got[b, j], want)
+    fps = ops.furthestsampling(torch.from_numpy(xyz).cuda(), 32).cpu().numpy()
+    for b in range(2):
+        temp = np.full(500, 1e10, np.float32)
+        last, want = 0, [0]
+        for _ in range(31):
+            d = xyz[b] - xyz[b][last]
+            d2 = ((d[:, 0] * d[:, 0]) + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            temp = np.minimum(temp, d2)
+            last = int(np.argmax(temp))
+            want.append(last)
+        assert np.array_equal(fps[b], np.array(want))
+
+
+def test_cpu_tensor_raises(ops):
+    with pytest.raises(RuntimeError):
+        ops.knn_batch(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), 1)
