@@ -45,6 +45,8 @@ SIGNATURES = {
     "gdm_match_workspace_bytes": (_sz, [_i, _i, _i]),
     "gdm_match_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

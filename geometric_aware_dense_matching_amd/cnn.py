@@ -1,0 +1,118 @@
+"""Image branch: ResNet-18 trunk + pyramid pooling + three x2 upsample stages.
+
+Stays on PyTorch-ROCm (MIOpen convolutions) -- SURVEY.md row a7: not a custom-kernel row.
+Module / parameter names equal the reference's so checkpoints load key for key:
+  /root/reference/models/cnn/extractors.py:107-200  ResNet(BasicBlock, [2,2,2,2])
+  /root/reference/models/cnn/pspnet.py:7-45,93-138  PSPModule, PSPUpsample, PSPNet
+
+Behaviour worth knowing (all reproduced):
+  * `_make_layer` is called with dilation=2/4 for layer3/4 but passes `self.current_dilation`
+    (still 1, because output_stride defaults to 32) to the blocks, so the trunk is a plain
+    stride-8 ResNet with NO dilation (extractors.py:151-177).
+  * `final` = Conv2d(64,64,1) + nn.LogSoftmax() with implicit dim, which is dim=1 for 4-D input
+    (pspnet.py:108-112).
+  * No ImageNet download: weights come from the checkpoint (the reference fetches them over the
+    network at construction, pspnet.py:141 -> extractors.py:203-212).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv3x3(cin, cout, stride=1, dilation=1):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, planes, stride=stride, dilation=dilation)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes, stride=1, dilation=dilation)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        out = out + residual
+        return self.relu(out)
+
+
+class ResNet18Trunk(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 2, stride=1)
+        self.layer2 = self._make_layer(128, 2, stride=2)
+        self.layer3 = self._make_layer(256, 2, stride=1)     # reference asks for dilation 2, gets 1
+        self.layer4 = self._make_layer(512, 2, stride=1)     # reference asks for dilation 4, gets 1
+        self.fc = nn.Linear(512, 1000)                       # unused; kept for checkpoint key parity
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+
+class PSPModule(nn.Module):
+    def __init__(self, features, out_features=1024, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([nn.Sequential(nn.AdaptiveAvgPool2d(output_size=(s, s)),
+                                                   nn.Conv2d(features, features, kernel_size=1, bias=False))
+                                     for s in sizes])
+        self.bottleneck = nn.Conv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
+        self.relu = nn.ReLU()
+
+    def forward(self, feats):
+        h, w = feats.size(2), feats.size(3)
+        priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=True)
+                  for stage in self.stages] + [feats]
+        return self.relu(self.bottleneck(torch.cat(priors, 1)))
+
+
+class PSPUpsample(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+                                  nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class PSPNet(nn.Module):
+    """pspnet.py:93-121 with the resnet18 settings of `psp_models['resnet18']` (:141); only the
+    sub-modules FFB6DEmb borrows are used, the rest exists for checkpoint key parity."""
+
+    def __init__(self):
+        super().__init__()
+        self.feats = ResNet18Trunk()
+        self.psp = PSPModule(512, 1024, (1, 2, 3, 6))
+        self.drop_1 = nn.Dropout2d(p=0.3)
+        self.up_1 = PSPUpsample(1024, 256)
+        self.up_2 = PSPUpsample(256, 64)
+        self.up_3 = PSPUpsample(64, 64)
+        self.drop_2 = nn.Dropout2d(p=0.15)
+        self.final = nn.Sequential(nn.Conv2d(64, 64, kernel_size=1), nn.LogSoftmax(dim=1))

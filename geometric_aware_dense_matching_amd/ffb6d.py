@@ -1,0 +1,145 @@
+"""FFB6DEmb: bidirectional fusion of the image branch and the RandLA point branch.
+
+Mirrors /root/reference/models/ffb6d.py:9-285 (constructor layout and parameter names identical,
+so `pcd_emb.*` checkpoint keys load unchanged; forward follows :172-285 stage by stage).
+
+HIP operators replace the reference's gather chains:
+  random_sample (:128-146)          -> ops.gather_max   (index read once, max over K in registers)
+  nearest_interpolation (:148-163)  -> ops.gather_nn
+  choose gather (:278-281)          -> ops.gather_nn
+Neighbour indices are consumed as int32 (int64 accepted and narrowed).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cnn import PSPNet
+from .layers import pt_conv2d, rl_conv1d, rl_conv2d
+from .randla import DilatedResBlock
+
+
+class FFB6DEmb(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        cnn = PSPNet()
+        d_outs = list(cfg.d_out)
+        n_layers = cfg.num_layers
+
+        self.cnn_pre_stages = nn.Sequential(cnn.feats.conv1, cnn.feats.bn1, cnn.feats.relu, cnn.feats.maxpool)
+        self.rndla_pre_stages = rl_conv1d(cfg.in_c, 8, bn=True)                  # RandLANet.py:19 fc0
+
+        self.cnn_ds_stages = nn.ModuleList([
+            cnn.feats.layer1,
+            cnn.feats.layer2,
+            nn.Sequential(cnn.feats.layer3, cnn.feats.layer4),
+            nn.Sequential(cnn.psp, cnn.drop_1),
+        ])
+        self.ds_sr = [4, 8, 8, 8]
+
+        blocks = nn.ModuleList()                                                 # RandLANet.py:21-26
+        d_in = 8
+        for i in range(n_layers):
+            blocks.append(DilatedResBlock(d_in, d_outs[i]))
+            d_in = 2 * d_outs[i]
+        self.rndla_ds_stages = blocks
+
+        self.ds_rgb_oc = [64, 128, 512, 1024]
+        self.ds_rndla_oc = [c * 2 for c in d_outs]
+        self.ds_fuse_r2p_pre_layers = nn.ModuleList()
+        self.ds_fuse_r2p_fuse_layers = nn.ModuleList()
+        self.ds_fuse_p2r_pre_layers = nn.ModuleList()
+        self.ds_fuse_p2r_fuse_layers = nn.ModuleList()
+        for i in range(4):
+            self.ds_fuse_r2p_pre_layers.append(pt_conv2d(self.ds_rgb_oc[i], self.ds_rndla_oc[i], bn=True))
+            self.ds_fuse_r2p_fuse_layers.append(pt_conv2d(self.ds_rndla_oc[i] * 2, self.ds_rndla_oc[i], bn=True))
+            self.ds_fuse_p2r_pre_layers.append(pt_conv2d(self.ds_rndla_oc[i], self.ds_rgb_oc[i], bn=True))
+            self.ds_fuse_p2r_fuse_layers.append(pt_conv2d(self.ds_rgb_oc[i] * 2, self.ds_rgb_oc[i], bn=True))
+
+        self.cnn_up_stages = nn.ModuleList([
+            nn.Sequential(cnn.up_1, cnn.drop_2),
+            nn.Sequential(cnn.up_2, cnn.drop_2),
+            nn.Sequential(cnn.final),
+            nn.Sequential(cnn.up_3, cnn.final),              # `final` is shared, as in the reference (:79-80)
+        ])
+        self.up_rgb_oc = [256, 64, 64]
+        self.up_rndla_oc = []
+        for j in range(n_layers):
+            self.up_rndla_oc.append(self.ds_rndla_oc[-j - 2] if j < 3 else self.ds_rndla_oc[0])
+
+        dec = nn.ModuleList()                                                    # RandLANet.py:28-39 decoder_blocks
+        d_out = 2 * d_outs[-1]
+        for j in range(n_layers):
+            if j < 3:
+                d_in = d_out + 2 * d_outs[-j - 2]
+                d_out = 2 * d_outs[-j - 2]
+            else:
+                d_in = 4 * d_outs[-4]
+                d_out = 2 * d_outs[-4]
+            dec.append(rl_conv2d(d_in, d_out, bn=True))
+        self.rndla_up_stages = dec
+
+        self.up_fuse_r2p_pre_layers = nn.ModuleList()
+        self.up_fuse_r2p_fuse_layers = nn.ModuleList()
+        self.up_fuse_p2r_pre_layers = nn.ModuleList()
+        self.up_fuse_p2r_fuse_layers = nn.ModuleList()
+        for i in range(3):
+            self.up_fuse_r2p_pre_layers.append(pt_conv2d(self.up_rgb_oc[i], self.up_rndla_oc[i], bn=True))
+            self.up_fuse_r2p_fuse_layers.append(pt_conv2d(self.up_rndla_oc[i] * 2, self.up_rndla_oc[i], bn=True))
+            self.up_fuse_p2r_pre_layers.append(pt_conv2d(self.up_rndla_oc[i], self.up_rgb_oc[i], bn=True))
+            self.up_fuse_p2r_fuse_layers.append(pt_conv2d(self.up_rgb_oc[i] * 2, self.up_rgb_oc[i], bn=True))
+
+    # same names and contracts as the reference's static methods (ffb6d.py:128-163)
+    @staticmethod
+    def random_sample(feature, pool_idx):
+        return ops.gather_max(feature, pool_idx).unsqueeze(3)
+
+    @staticmethod
+    def nearest_interpolation(feature, interp_idx):
+        return ops.gather_nn(feature, interp_idx).unsqueeze(3)
+
+    def forward(self, inputs, end_points=None):
+        rgb_emb = self.cnn_pre_stages(inputs["rgb"])
+        p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
+
+        ds_emb = []
+        for i_ds in range(4):
+            rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
+            bs, c, hr, wr = rgb_emb0.size()
+
+            f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
+            p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
+            if i_ds == 0:
+                ds_emb.append(f_encoder_i)
+
+            p2r_emb = self.ds_fuse_p2r_pre_layers[i_ds](p_emb0)
+            p2r_emb = self.nearest_interpolation(p2r_emb, inputs["p2r_ds_nei_idx%d" % i_ds]).view(bs, -1, hr, wr)
+            rgb_emb = self.ds_fuse_p2r_fuse_layers[i_ds](torch.cat((rgb_emb0, p2r_emb), dim=1))
+
+            r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
+            r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
+            p_emb = self.ds_fuse_r2p_fuse_layers[i_ds](torch.cat((p_emb0, r2p_emb), dim=1))
+            ds_emb.append(p_emb)
+
+        n_up = len(self.rndla_up_stages)
+        for i_up in range(n_up - 1):
+            rgb_emb0 = self.cnn_up_stages[i_up](rgb_emb)
+            bs, c, hr, wr = rgb_emb0.size()
+
+            f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])
+            p_emb0 = self.rndla_up_stages[i_up](torch.cat([ds_emb[-i_up - 2], f_interp_i], dim=1))
+
+            p2r_emb = self.up_fuse_p2r_pre_layers[i_up](p_emb0)
+            p2r_emb = self.nearest_interpolation(p2r_emb, inputs["p2r_up_nei_idx%d" % i_up]).view(bs, -1, hr, wr)
+            rgb_emb = self.up_fuse_p2r_fuse_layers[i_up](torch.cat((rgb_emb0, p2r_emb), dim=1))
+
+            r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_up_nei_idx%d" % i_up])
+            r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)
+            p_emb = self.up_fuse_r2p_fuse_layers[i_up](torch.cat((p_emb0, r2p_emb), dim=1))
+
+        rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
+        f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx0"])
+        p_emb = self.rndla_up_stages[n_up - 1](torch.cat([ds_emb[0], f_interp_i], dim=1)).squeeze(-1)
+
+        bs, di, _, _ = rgb_emb.size()
+        rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+        return torch.cat([rgb_emb_c, p_emb], dim=1)

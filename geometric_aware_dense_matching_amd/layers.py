@@ -1,0 +1,93 @@
+"""conv(+BN)(+activation) building blocks whose parameter names equal the reference's, so that a
+reference checkpoint (`model_state` of /root/reference/train_lm.py:102-117) loads key for key.
+
+Two flavours exist in the reference and both are needed:
+  * models/pytorch_utils.py:70-124      submodules `conv`, `normlayer.bn`, `activation`;
+    default activation ReLU, torch-default BN (eps 1e-5, momentum 0.1); bias dropped when bn (:90)
+  * models/RandLA/pytorch_utils.py:34-99 submodules `conv`, `bn.bn`, `activation`;
+    default activation LeakyReLU(0.2); BN eps 1e-6, momentum 0.99 (:103-105)
+"""
+import torch.nn as nn
+
+
+class _BN(nn.Sequential):
+    def __init__(self, bn_cls, channels, **kw):
+        super().__init__()
+        self.add_module("bn", bn_cls(channels, **kw))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0.0)
+
+
+class _PtConv(nn.Sequential):
+    """models/pytorch_utils.py:_ConvBase (non-preact form, the only one the hot path uses)."""
+
+    def __init__(self, conv_cls, bn_cls, cin, cout, kernel_size, bn, activation, bias):
+        super().__init__()
+        bias = bias and (not bn)
+        conv = conv_cls(cin, cout, kernel_size=kernel_size, bias=bias)
+        nn.init.kaiming_normal_(conv.weight)
+        if bias:
+            nn.init.constant_(conv.bias, 0)
+        self.add_module("conv", conv)
+        if bn:
+            self.add_module("normlayer", _BN(bn_cls, cout))
+        if activation is not None:
+            self.add_module("activation", activation)
+
+
+_RELU = object()
+
+
+def pt_conv1d(cin, cout, bn=False, activation=_RELU, bias=True):
+    act = nn.ReLU(inplace=True) if activation is _RELU else activation
+    return _PtConv(nn.Conv1d, nn.BatchNorm1d, cin, cout, 1, bn, act, bias)
+
+
+def pt_conv2d(cin, cout, bn=False, activation=_RELU, bias=True):
+    act = nn.ReLU(inplace=True) if activation is _RELU else activation
+    return _PtConv(nn.Conv2d, nn.BatchNorm2d, cin, cout, (1, 1), bn, act, bias)
+
+
+class PtSeq(nn.Sequential):
+    """models/pytorch_utils.py:270-316 `Seq(...).conv1d(...)` chains: children named "0", "1", ..."""
+
+    def __init__(self, input_channels):
+        super().__init__()
+        self.count = 0
+        self.current_channels = input_channels
+
+    def conv1d(self, out_size, bn=False, activation=_RELU, bias=True):
+        self.add_module(str(self.count), pt_conv1d(self.current_channels, out_size, bn=bn, activation=activation, bias=bias))
+        self.count += 1
+        self.current_channels = out_size
+        return self
+
+
+class _RlConv(nn.Sequential):
+    """models/RandLA/pytorch_utils.py:_ConvBase (non-preact, no instance norm)."""
+
+    def __init__(self, conv_cls, bn_cls, cin, cout, kernel_size, bn, activation, bias=True):
+        super().__init__()
+        bias = bias and (not bn)
+        conv = conv_cls(cin, cout, kernel_size=kernel_size, bias=bias)
+        nn.init.kaiming_normal_(conv.weight)
+        if bias:
+            nn.init.constant_(conv.bias, 0)
+        self.add_module("conv", conv)
+        if bn:
+            self.add_module("bn", _BN(bn_cls, cout, eps=1e-6, momentum=0.99))
+        if activation is not None:
+            self.add_module("activation", activation)
+
+
+_LRELU = object()
+
+
+def rl_conv1d(cin, cout, bn=False, activation=_LRELU):
+    act = nn.LeakyReLU(negative_slope=0.2, inplace=True) if activation is _LRELU else activation
+    return _RlConv(nn.Conv1d, nn.BatchNorm1d, cin, cout, 1, bn, act)
+
+
+def rl_conv2d(cin, cout, bn=False, activation=_LRELU):
+    act = nn.LeakyReLU(negative_slope=0.2, inplace=True) if activation is _LRELU else activation
+    return _RlConv(nn.Conv2d, nn.BatchNorm2d, cin, cout, (1, 1), bn, act)

@@ -1,0 +1,61 @@
+"""Neighbour pyramid on the GPU: the 22 exact-kNN searches per crop that the reference runs on the
+CPU inside DataLoader workers (/root/reference/datasets/lm/linemod_pbr.py:515-569, the ycbv copy
+ycbv_pbr.py:541-574), for a whole batch of crops, in TWO kernel launches (one per K class).
+
+Input : cld  f32[B,N,3]   sampled scene points (first three rows of cld_rgb_nrm, transposed)
+        dpt_xyz f32[B,S,S,3] the crop's per-pixel xyz map (dpt_xyz_clip)
+Output: the 30 arrays the model consumes, batched, on the device; indices int32:
+        cld_xyz{0-3} cld_nei_idx{0-3} cld_sub_idx{0-3} cld_interp_idx{0-3}
+        r2p_ds_nei_idx{0-3} p2r_ds_nei_idx{0-3} r2p_up_nei_idx{0-2} p2r_up_nei_idx{0-2}
+
+"Random" sub-sampling is a prefix slice of the pre-shuffled cloud (linemod_pbr.py:538), so all 22
+searches depend only on the inputs and are independent of each other: they run concurrently.
+"""
+import torch
+
+from . import ops
+
+RGB_DS_SR = (4, 8, 8, 8)       # linemod_pbr.py:529
+PCLD_SUB_SR = (4, 4, 4, 4)     # linemod_pbr.py:531
+RGB_UP_SR = (4, 2, 2)          # linemod_pbr.py:556
+K_NEI = 16
+
+
+def cloud_from_inputs(cld_rgb_nrm):
+    """cld_rgb_nrm f32[B,9,N] -> xyz f32[B,N,3] contiguous."""
+    return cld_rgb_nrm[:, :3, :].transpose(1, 2).contiguous()
+
+
+def build_pyramid(cld, dpt_xyz):
+    if not (cld.is_cuda and dpt_xyz.is_cuda):
+        raise RuntimeError("build_pyramid runs on the GPU (HIP kNN); there is no CPU fallback")
+    B, N, _ = cld.shape
+    S = dpt_xyz.shape[1]
+    assert dpt_xyz.shape == (B, S, S, 3)
+    if N % 256 != 0 or N < 1024:
+        raise ValueError("N=%d: four /4 levels must leave >= 16 points (N >= 1024, N %% 256 == 0)" % N)
+    cld = cld.contiguous()
+    grids = {1: dpt_xyz.reshape(B, S * S, 3)}
+    for sc in (2, 4, 8):                                   # linemod_pbr.py:517-527 strided xyz maps
+        grids[sc] = dpt_xyz[:, ::sc, ::sc, :].reshape(B, -1, 3).contiguous()
+
+    levels = [cld]
+    for i in range(4):
+        levels.append(cld[:, : levels[-1].shape[1] // PCLD_SUB_SR[i]])      # prefix views, batch stride kept
+
+    jobs, names = [], []
+    for i in range(4):
+        cur, sub, px = levels[i], levels[i + 1], grids[RGB_DS_SR[i]]
+        jobs += [(cur, cur, K_NEI), (sub, cur, 1), (px, sub, K_NEI), (sub, px, 1)]
+        names += ["cld_nei_idx%d" % i, "cld_interp_idx%d" % i, "r2p_ds_nei_idx%d" % i, "p2r_ds_nei_idx%d" % i]
+    for i in range(3):
+        pts, px = levels[3 - i], grids[RGB_UP_SR[i]]
+        jobs += [(px, pts, K_NEI), (pts, px, 1)]
+        names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
+    outs = ops.knn_jobs(jobs, B)
+
+    pyr = dict(zip(names, outs))
+    for i in range(4):
+        pyr["cld_xyz%d" % i] = levels[i]
+        pyr["cld_sub_idx%d" % i] = pyr["cld_nei_idx%d" % i][:, : levels[i + 1].shape[1]]
+    return pyr

@@ -1,0 +1,66 @@
+"""RandLA-Net local feature aggregation blocks on the HIP gather / pooling kernels.
+
+Mirrors (names, shapes, semantics) /root/reference/models/RandLA/RandLANet.py:
+  Dilated_res_block :674-688   Building_block :691-738   Att_pooling :741-754
+Only these blocks are used by the geoMatch path (models/ffb6d.py:28,40,90).
+
+What changes versus the reference is HOW the neighbour access runs: instead of
+permute -> index.repeat over channels -> torch.gather -> permute -> contiguous (five passes and an
+int64 index of B*n*K*C elements), one HIP kernel reads the int32 index row once and writes the
+channel-major [B,C,n,K] tensor directly (ops.group_gather), the 10-channel relative position
+encoding is one kernel (ops.rel_pos_enc), and softmax-over-K * feature -> sum is one kernel
+(ops.att_pool).  Features stay [B,C,n,1] / [B,C,n,K] channel-major exactly as in the reference,
+so the 1x1 convolutions are unchanged MIOpen/rocBLAS GEMMs.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import rl_conv2d
+
+
+class AttPooling(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.fc = nn.Conv2d(d_in, d_in, (1, 1), bias=False)
+        self.mlp = rl_conv2d(d_in, d_out, bn=True)
+
+    def forward(self, feature_set):                       # [B,C,n,K]
+        att_activation = self.fc(feature_set)
+        f_agg = ops.att_pool(att_activation, feature_set)  # [B,C,n]
+        return self.mlp(f_agg.unsqueeze(3))
+
+
+class BuildingBlock(nn.Module):
+    def __init__(self, d_out):
+        super().__init__()
+        self.mlp1 = rl_conv2d(10, d_out // 2, bn=True)
+        self.att_pooling_1 = AttPooling(d_out, d_out // 2)
+        self.mlp2 = rl_conv2d(d_out // 2, d_out // 2, bn=True)
+        self.att_pooling_2 = AttPooling(d_out, d_out)
+
+    def forward(self, xyz, feature, neigh_idx):            # feature [B,C,n,1]
+        f_xyz = ops.rel_pos_enc(xyz, neigh_idx)             # [B,10,n,K]
+        f_xyz = self.mlp1(f_xyz)
+        f_neighbours = ops.group_gather(feature, neigh_idx)  # [B,C,n,K]
+        f_pc_agg = self.att_pooling_1(torch.cat([f_neighbours, f_xyz], dim=1))
+        f_xyz = self.mlp2(f_xyz)
+        f_neighbours = ops.group_gather(f_pc_agg, neigh_idx)
+        return self.att_pooling_2(torch.cat([f_neighbours, f_xyz], dim=1))
+
+
+class DilatedResBlock(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.mlp1 = rl_conv2d(d_in, d_out // 2, bn=True)
+        self.lfa = BuildingBlock(d_out)
+        self.mlp2 = rl_conv2d(d_out, d_out * 2, bn=True, activation=None)
+        self.shortcut = rl_conv2d(d_in, d_out * 2, bn=True, activation=None)
+
+    def forward(self, feature, xyz, neigh_idx):
+        f_pc = self.mlp1(feature)
+        f_pc = self.lfa(xyz, f_pc, neigh_idx)
+        f_pc = self.mlp2(f_pc)
+        shortcut = self.shortcut(feature)
+        return F.leaky_relu(f_pc + shortcut, negative_slope=0.2)

@@ -120,7 +120,10 @@ def synthetic_state_dict(template, seed=0):
     out = {}
     for name, t in template.items():
         shape = tuple(t.shape)
-        h = int.from_bytes(hashlib.sha256((name + "|%d" % seed).encode()).digest()[:4], "little")
+        # `final` is ONE module registered under two names (models/ffb6d.py:79-80): a real checkpoint
+        # holds identical tensors under both, so both names must hash alike.
+        canon = name.replace("cnn_up_stages.2.0.", "cnn_up_stages.3.1.")
+        h = int.from_bytes(hashlib.sha256((canon + "|%d" % seed).encode()).digest()[:4], "little")
         rs = np.random.RandomState(h)
         if name.endswith("num_batches_tracked"):
             out[name] = torch.tensor(1, dtype=torch.long)
@@ -134,10 +137,12 @@ def synthetic_state_dict(template, seed=0):
             a = 0.1 * rs.randn(*shape)
         elif name.endswith("bias"):
             a = 0.05 * rs.randn(*shape)
+        elif len(shape) == 1 and shape[0] == 1:
+            a = 0.25 + 0.05 * rs.rand(*shape)                 # PReLU slope
         elif len(shape) == 1:
-            a = 1.0 + 0.1 * rs.randn(*shape)                  # BN gamma / PReLU slope / awl params
+            a = 1.0 + 0.1 * rs.randn(*shape)                  # BN gamma / awl params
         else:
             fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
-            a = rs.randn(*shape) * np.sqrt(2.0 / max(fan_in, 1))
+            a = rs.randn(*shape) * np.sqrt(1.0 / max(fan_in, 1))
         out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape))
     return out

@@ -142,6 +142,19 @@ int gdm_match_hip(const float* scene, const float* model, int B, int D, int N, i
  * count i32[B] of selected points (zeroed inside).                                        */
 int gdm_seg_mask_hip(const float* seg, int B, int N, uint8_t* mask, int32_t* count, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SplineConv sparse part for the object-model branch (models/SplineCNN.py:136-140,234-239;
+ * arithmetic of the un-vendored torch_spline_conv, dim=3, degree 1, open splines, mean aggr).
+ * xw f32[M, ks^3, C] = X @ [W_0|...|W_{ks^3-1}] (dense GEMM done by the caller),
+ * CSR edges sorted by target: rowptr i32[M+1], src i32[E], attr f32[E,3] in [0,1],
+ * root f32[M,C] (x W_root) or NULL, bias f32[C] or NULL -> out f32[M,C] (optional ReLU).     */
+int gdm_spline_aggregate_hip(const float* xw, const int32_t* rowptr, const int32_t* src, const float* attr,
+                             const float* root, const float* bias, int M, int C, int kernel_size, int relu,
+                             float* out, void* stream);
+/* grad_xw[src, wi_s, :] += b_s * grad_out[target, :] / deg(target); grad_xw zeroed by the caller. */
+int gdm_spline_aggregate_bwd_hip(const float* grad_out, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                 int M, int C, int kernel_size, float* grad_xw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""Deterministic input recipes shared by make_golden.py (run against the reference, here) and
+the tests (run anywhere).  Only numpy RandomState streams: the golden .npz files then need to
+hold outputs only."""
+import numpy as np
+
+
+def matching_inputs(Ne=1024, Me=4096, seed=13):
+    rs = np.random.RandomState(seed)
+    return dict(
+        seg_features=rs.randn(2, Ne).astype(np.float32),
+        rgbd_features=(rs.randn(128, Ne) * (0.5 + rs.rand(1, Ne))).astype(np.float32),
+        mesh_features=rs.randn(128, Me).astype(np.float32),
+        cld=rs.rand(9, Ne).astype(np.float32),
+    )
+
+
+def loss_inputs(M=512, Bl=2, Nl=256, seed=11):
+    rs = np.random.RandomState(seed)
+    d = dict(
+        rgbd_f=rs.randn(Bl, 128, Nl).astype(np.float32),
+        mesh_f=rs.randn(1, 128, M).astype(np.float32),
+        labels=(rs.rand(Bl, Nl) < 0.6).astype(np.int64),
+        match_idx=rs.randint(0, M + 1, size=(Bl, Nl)).astype(np.int64),
+        vis=(rs.rand(Bl, M) < 0.5).astype(np.float32),
+        seg=rs.randn(Bl, 2, Nl).astype(np.float32),
+        sim=(rs.rand(64, 100).astype(np.float32) * 2 - 1),
+    )
+    msk = rs.rand(64, 100) < 0.1
+    msk[:, 0] = True
+    d["mask"] = msk
+    return d
+
+
+def block_inputs(B=2, n=128, K=16, seed=7):
+    rs = np.random.RandomState(seed)
+    return dict(
+        xyz=rs.rand(B, n, 3).astype(np.float32),
+        feat8=rs.randn(B, 8, n, 1).astype(np.float32),
+        fset=rs.randn(B, 32, n, K).astype(np.float32),
+    )

@@ -1,0 +1,76 @@
+"""CPU: host-side mirror of the reference interface -- module tree, state_dict names/shapes, checkpoint
+format, input validation.  No kernels run here."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from geometric_aware_dense_matching_amd import synthetic
+from geometric_aware_dense_matching_amd.config import ConfigRandLA, make_model_cfg
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def model():
+    from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+    cfg = make_model_cfg(n_mesh_node=512)
+    return GeoMatch(cfg, 1, model_points=synthetic.make_model_points(1, 512))
+
+
+def test_state_dict_names_and_shapes_equal_the_reference(model):
+    want = json.load(open(os.path.join(G, "geomatch_state.json")))
+    got = {k: list(v.shape) for k, v in model.state_dict().items() if not k.startswith("model_emb.")}
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == want[k], k
+
+
+def test_mesh_branch_parameter_layout(model):
+    sd = model.model_emb.state_dict()
+    for i, cin in enumerate((9, 128, 128)):
+        assert list(sd["mesh_convs.%d.weight" % i].shape) == [125, cin, 128]
+        assert list(sd["mesh_convs.%d.lin.weight" % i].shape) == [128, cin]
+        assert list(sd["mesh_convs.%d.bias" % i].shape) == [128]
+    assert list(sd["mesh_final.weight"].shape) == [128, 9 + 3 * 128]
+    for b in ("xyz", "mesh_graph_x", "mesh_graph_edge_index", "mesh_graph_edge_attr", "const_one"):
+        assert b in sd
+    assert list(sd["mesh_graph_edge_index"].shape) == [2, 4 * 512]
+
+
+def test_reference_style_checkpoint_round_trip(model, tmp_path):
+    """train_lm.py:102-146: {'epoch','model_state','optimizer_state'}, optional 'module.' prefix."""
+    from geometric_aware_dense_matching_amd.checkpoint import load_checkpoint, save_checkpoint
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    path = save_checkpoint(model, opt, epoch=7, log_dir=str(tmp_path), obj_name="ape")
+    assert path.endswith(os.path.join("ape", "geomatch_07.pth.tar"))
+    assert os.path.exists(os.path.join(str(tmp_path), "ape", "geomatch.pth.tar"))
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) >= {"epoch", "model_state", "optimizer_state"}
+    ck["model_state"] = {"module." + k: v for k, v in ck["model_state"].items()}      # DDP-saved form
+    torch.save(ck, path)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    ep = load_checkpoint(model, None, os.path.join(str(tmp_path), "ape", "geomatch_07"))
+    assert ep == 7
+    ref = torch.load(path, map_location="cpu", weights_only=False)["model_state"]
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ref["module." + k]), k
+
+
+def test_forward_on_cpu_fails_loudly(model):
+    from oracle import pyramid as opyr
+    batch = synthetic.make_batch(seed=1, batch=1, n_points=1024)
+    inputs = {k: torch.from_numpy(v) for k, v in batch.items()}
+    pyr = opyr.build_pyramid(batch["cld_rgb_nrm"][0, :3].T.copy(), batch["dpt_xyz"][0])
+    inputs.update({k: torch.from_numpy(v[None]) for k, v in pyr.items()})
+    with pytest.raises(RuntimeError, match="no CPU fallback|GPU"):
+        model.eval()(inputs)
+
+
+def test_randla_config_defaults():
+    c = ConfigRandLA()
+    assert c.k_n == 16 and c.num_layers == 4 and c.in_c == 9 and list(c.d_out) == [32, 64, 128, 256]
