@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- RGB-D crops/s through the geoMatch hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic crops already resident in HBM:
+    neighbour pyramid (22 exact kNN per crop, HIP)  ->  GeoMatch.forward (eval; HIP gathers + MIOpen)
+    ->  N x M descriptor matching (fused normalise + MFMA similarity + row arg-max, HIP)
+Workload at N GPUs: BASELINE.json configs[1] per GPU (LineMOD obj_01, batch 16, N=2048 scene points x
+M=8192 model vertices, crop 256x256), one process per GPU, crops sharded across ranks with no
+data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="crops per GPU per step (configs[1]: 16)")
+    ap.add_argument("--npoints", type=int, default=2048)
+    ap.add_argument("--mesh", type=int, default=8192)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"])
+    ap.add_argument("--cache-mesh", action="store_true", help="reuse the (input independent) mesh descriptors in eval")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crops", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
+    """Reference CPU path as the oracle restates it (kNN leg through the compiled reference nanoflann when
+    oracle/_ref travelled with the snapshot): pyramid + FFB6DEmb + heads + matching, all host cores."""
+    import numpy as np
+    import torch
+    from oracle import knn as oknn, model_ref, ops_ref, pyramid as opyr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    use_ref = oknn.have_ref()
+    search = opyr.ref_knn_search if use_ref else None
+    t0 = time.perf_counter()
+    for i in range(n_crops):
+        pyr = opyr.build_pyramid(batch["cld_rgb_nrm"][i, :3].T.copy(), batch["dpt_xyz"][i], knn_search=search)
+        inp = {k: torch.from_numpy(batch[k][i:i + 1]) for k in ("rgb", "cld_rgb_nrm", "choose")}
+        inp.update({k: torch.from_numpy(v[None]) for k, v in pyr.items()})
+        with torch.no_grad():
+            out = model_ref.geomatch_forward(sd_cpu, inp, mesh_cpu)
+            msk = ops_ref.seg_mask(out["seg"][0])
+            ops_ref.match_argmax(out["rgbd"][0], mesh_cpu, msk if int(msk.sum()) > 1 else None)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_crops / dt, 4), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": "%d crops of the same workload (N=%d x M=%d): %s kNN pyramid (1 thread/call as shipped) + oracle torch-CPU "
+                      "FFB6DEmb+heads + matching on %d threads; mesh branch excluded (third-party op)" %
+                      (n_crops, batch["cld_rgb_nrm"].shape[2], mesh_cpu.shape[1],
+                       "compiled reference nanoflann" if use_ref else "oracle brute-force", cores)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from geometric_aware_dense_matching_amd import matching, ops, pyramid, synthetic
+    from geometric_aware_dense_matching_amd.config import make_model_cfg
+    from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv kernels during warmup
+
+    B, N, M = args.batch, args.npoints, args.mesh
+    torch.manual_seed(0)
+    model = GeoMatch(make_model_cfg(n_mesh_node=M, num_points=N), 1, model_points=synthetic.make_model_points(1, M),
+                     cache_mesh_in_eval=args.cache_mesh)
+    tmpl = {k: v for k, v in model.state_dict().items()
+            if not k.startswith("model_emb.mesh_graph") and k not in ("model_emb.xyz", "model_emb.const_one")}
+    sd = synthetic.synthetic_state_dict(tmpl, seed=0)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+
+    batch = synthetic.make_batch(seed=100 + rank, batch=B, n_points=N)
+    inputs = {k: torch.from_numpy(batch[k]).to(dev) for k in ("rgb", "cld_rgb_nrm", "choose")}
+    dpt_xyz = torch.from_numpy(batch["dpt_xyz"]).to(dev)
+    cld = pyramid.cloud_from_inputs(inputs["cld_rgb_nrm"])
+    prec = ops.MATCH_BF16X3 if args.precision == "bf16x3" else ops.MATCH_F32
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stage_ev = []
+
+    def step(record=False):
+        if record:
+            e = [ev() for _ in range(5)]
+            e[0].record()
+        pyr = pyramid.build_pyramid(cld, dpt_xyz)
+        if record:
+            e[1].record()
+        d = dict(inputs)
+        d.update(pyr)
+        ep = model(d)
+        if record:
+            e[2].record()
+        mask, count = ops.seg_mask(ep["seg"])
+        srows = ops.match_pack(ep["rgbd"], prec)
+        mrows = ops.match_pack(ep["mesh"][0], prec)
+        if record:
+            e[3].record()
+        bi, bs = ops.match_packed(srows, mrows, B, N, M, prec)
+        if record:
+            e[4].record()
+            stage_ev.append(e)
+        return bi, bs, mask
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(record=True)
+        sync_all()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    stages = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in stage_ev])   # ms
+    pyr_ms, fwd_ms, pack_ms, match_ms = stages.mean(axis=0).tolist()
+
+    # ---- roofline of the N x M descriptor kernel -------------------------------------
+    flops = 2.0 * B * N * M * 128
+    fused_bytes = 4.0 * 128 * (B * N + M) + 8.0 * B * N
+    mat_bytes = 4.0 * 128 * (B * N + M) + 4.0 * B * N * M
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16x3" else MFMA_F32_PEAK_TFLOPS
+    mfma_flops = flops * (3.0 if args.precision == "bf16x3" else 1.0)    # executed MFMA work: hi*hi + hi*lo + lo*hi
+    roofline_fused = {"kernel": "match_kernel<fused arg-max> (+ split merge), in the timed region", "bound": "mfma",
+                      "achieved": round(mfma_flops / (match_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                      "frac": round(mfma_flops / (match_ms * 1e-3) / 1e12 / peak_tf, 4),
+                      "algorithmic_tflops": round(flops / (match_ms * 1e-3) / 1e12, 2),
+                      "avg_ms": round(match_ms, 4), "traffic": None}
+    with torch.no_grad():
+        ep_rgbd, ep_mesh = None, None
+        d = dict(inputs)
+        d.update(pyramid.build_pyramid(cld, dpt_xyz))
+        ep = model(d)
+        srows = ops.match_pack(ep["rgbd"], prec)
+        mrows = ops.match_pack(ep["mesh"][0], prec)
+        sim = torch.empty((B, N, M), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(max(args.steps, 10)):
+            a, b = ev(), ev()
+            a.record()
+            ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        mat_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        del sim
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "match_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("materialised_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "match_kernel<materialised sim> (N x 8192 descriptor-distance kernel)", "bound": "hbm",
+                "achieved": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(mat_bytes / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": mat_bytes, "avg_ms": round(mat_ms, 4),
+                "mfma_tflops": round(mfma_flops / (mat_ms * 1e-3) / 1e12, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cpu = cpu_baseline(batch, sd_cpu, ep["mesh"][0].detach().cpu(), min(args.cpu_crops, B))
+
+    if rank == 0:
+        line = {
+            "metric": "rgbd_crops_per_sec_geomatch_fwd", "value": round(value, 2), "unit": "crops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LineMOD obj_01 batch=%d/GPU, N=%d scene pts x M=%d model kps, crop 256x256, geoMatch "
+                                   "(CNN+RandLA+SplineCNN) fwd-only + kNN pyramid + matching" % (B, N, M),
+                       "batch_per_gpu": B, "global_batch": B * world, "n_points": N, "n_model": M,
+                       "match_precision": args.precision, "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
+            "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
+                         "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
+            "roofline": roofline, "roofline_fused": roofline_fused, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,10 @@ SIGNATURES = {
     "gdm_att_pool_bwd_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_match_workspace_bytes": (_sz, [_i, _i, _i]),
     "gdm_match_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdm_match_rows_bytes": (_sz, [_i]),
+    "gdm_match_partial_bytes": (_sz, [_i, _i]),
+    "gdm_match_pack_hip": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_match_packed_hip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

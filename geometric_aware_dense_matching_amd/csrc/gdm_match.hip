@@ -301,46 +301,56 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 } // namespace
 
+extern "C" size_t gdm_match_rows_bytes(int rows)
+{
+    return rows < 1 ? 0 : align256((size_t)rows * ROW_BYTES);
+}
+
+extern "C" size_t gdm_match_partial_bytes(int B, int N)
+{
+    if (B < 1 || N < 1) return 0;
+    return 2 * align256(64 * (size_t)B * N * sizeof(float));
+}
+
 extern "C" size_t gdm_match_workspace_bytes(int B, int N, int M)
 {
     if (B < 1 || N < 1 || M < 1) return 0;
-    const size_t R = (size_t)B * N;
-    return align256(R * ROW_BYTES) + align256((size_t)M * ROW_BYTES) + 2 * align256(64 * R * sizeof(float)) + 256;
+    return gdm_match_rows_bytes(B * N) + gdm_match_rows_bytes(M) + gdm_match_partial_bytes(B, N) + 256;
 }
 
-extern "C" int gdm_match_hip(const float* scene, const float* model, int B, int Dd, int N, int M, int precision,
-                             int32_t* best_idx, float* best_sim, float* sim,
-                             void* workspace, size_t workspace_bytes, void* stream_)
+extern "C" int gdm_match_pack_hip(const float* x, int R, int Dd, int n, int precision, void* rows, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    GDM_CHECK_ARG(scene && model && best_idx && best_sim && workspace, "gdm_match_hip: NULL pointer");
-    GDM_CHECK_ARG(Dd == D, "gdm_match_hip: D=%d, only D=128 is built", Dd);
-    GDM_CHECK_ARG(B >= 1 && N >= 1 && M >= 1, "gdm_match_hip: bad shape B=%d N=%d M=%d", B, N, M);
-    GDM_CHECK_ARG(precision == GDM_MATCH_BF16X3 || precision == GDM_MATCH_F32, "gdm_match_hip: precision=%d", precision);
-    GDM_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "gdm_match_hip: workspace must be 16-byte aligned");
-    if (workspace_bytes < gdm_match_workspace_bytes(B, N, M)) {
-        gdm_set_error("gdm_match_hip: workspace %zu < %zu bytes", workspace_bytes, gdm_match_workspace_bytes(B, N, M));
+    GDM_CHECK_ARG(x && rows, "gdm_match_pack_hip: NULL pointer");
+    GDM_CHECK_ARG(Dd == D, "gdm_match_pack_hip: D=%d, only D=128 is built", Dd);
+    GDM_CHECK_ARG(R >= 1 && R <= 65535 && n >= 1, "gdm_match_pack_hip: bad shape R=%d n=%d", R, n);
+    GDM_CHECK_ARG(precision == GDM_MATCH_BF16X3 || precision == GDM_MATCH_F32, "gdm_match_pack_hip: precision=%d", precision);
+    GDM_CHECK_ARG(((uintptr_t)rows & 15) == 0, "gdm_match_pack_hip: rows must be 16-byte aligned");
+    dim3 grid(gdm_cdiv(n, 64), R);
+    if (precision == GDM_MATCH_BF16X3)
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_BF16X3>, grid, dim3(256), 0, stream, x, n, (unsigned char*)rows);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_F32>, grid, dim3(256), 0, stream, x, n, (unsigned char*)rows);
+    return gdm_launch_status("pack_rows_kernel");
+}
+
+extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_rows, int R, int M, int precision,
+                                    int32_t* best_idx, float* best_sim, float* sim,
+                                    void* partial, size_t partial_bytes, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    GDM_CHECK_ARG(scene_rows && model_rows && best_idx && best_sim && partial, "gdm_match_packed_hip: NULL pointer");
+    GDM_CHECK_ARG(R >= 1 && M >= 1, "gdm_match_packed_hip: bad shape R=%d M=%d", R, M);
+    GDM_CHECK_ARG(precision == GDM_MATCH_BF16X3 || precision == GDM_MATCH_F32, "gdm_match_packed_hip: precision=%d", precision);
+    const size_t half = align256(64 * (size_t)R * sizeof(float));
+    if (partial_bytes < 2 * half) {
+        gdm_set_error("gdm_match_packed_hip: partial workspace %zu < %zu bytes", partial_bytes, 2 * half);
         return GDM_ENOMEM;
     }
-    GDM_CHECK_ARG((long)B * N < (1L << 31) / ROW_BYTES * ROW_BYTES, "gdm_match_hip: B*N too large");
-    const int R = B * N;
-    unsigned char* ws = (unsigned char*)workspace;
-    unsigned char* apk = ws;
-    unsigned char* bpk = apk + align256((size_t)R * ROW_BYTES);
-    float* pval = (float*)(bpk + align256((size_t)M * ROW_BYTES));
-    int32_t* pidx = (int32_t*)((unsigned char*)pval + align256(64 * (size_t)R * sizeof(float)));
-
-    dim3 pg_s(gdm_cdiv(N, 64), B), pg_m(gdm_cdiv(M, 64), 1);
-    GDM_CHECK_ARG(B <= 65535, "gdm_match_hip: B too large");
-    if (precision == GDM_MATCH_BF16X3) {
-        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_BF16X3>, pg_s, dim3(256), 0, stream, scene, N, apk);
-        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_BF16X3>, pg_m, dim3(256), 0, stream, model, M, bpk);
-    } else {
-        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_F32>, pg_s, dim3(256), 0, stream, scene, N, apk);
-        hipLaunchKernelGGL(pack_rows_kernel<GDM_MATCH_F32>, pg_m, dim3(256), 0, stream, model, M, bpk);
-    }
-    int rc = gdm_launch_status("pack_rows_kernel");
-    if (rc) return rc;
+    const unsigned char* apk = (const unsigned char*)scene_rows;
+    const unsigned char* bpk = (const unsigned char*)model_rows;
+    float* pval = (float*)partial;
+    int32_t* pidx = (int32_t*)((unsigned char*)partial + half);
 
     const bool ws_sim = sim != nullptr;
     const int splits = pick_splits(R, M, ws_sim);
@@ -357,11 +367,35 @@ extern "C" int gdm_match_hip(const float* scene, const float* model, int B, int 
         if (ws_sim) LAUNCH(GDM_MATCH_F32, true); else LAUNCH(GDM_MATCH_F32, false);
     }
 #undef LAUNCH
-    rc = gdm_launch_status("match_kernel");
+    int rc = gdm_launch_status("match_kernel");
     if (rc) return rc;
     if (nsplit > 1) {
         hipLaunchKernelGGL(merge_splits_kernel, dim3(gdm_cdiv(R, 256)), dim3(256), 0, stream, pval, pidx, nsplit, R, best_sim, best_idx);
         rc = gdm_launch_status("merge_splits_kernel");
     }
     return rc;
+}
+
+extern "C" int gdm_match_hip(const float* scene, const float* model, int B, int Dd, int N, int M, int precision,
+                             int32_t* best_idx, float* best_sim, float* sim,
+                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    GDM_CHECK_ARG(scene && model && best_idx && best_sim && workspace, "gdm_match_hip: NULL pointer");
+    GDM_CHECK_ARG(Dd == D, "gdm_match_hip: D=%d, only D=128 is built", Dd);
+    GDM_CHECK_ARG(B >= 1 && N >= 1 && M >= 1, "gdm_match_hip: bad shape B=%d N=%d M=%d", B, N, M);
+    GDM_CHECK_ARG((long)B * N < (1L << 22), "gdm_match_hip: B*N too large");
+    GDM_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "gdm_match_hip: workspace must be 16-byte aligned");
+    if (workspace_bytes < gdm_match_workspace_bytes(B, N, M)) {
+        gdm_set_error("gdm_match_hip: workspace %zu < %zu bytes", workspace_bytes, gdm_match_workspace_bytes(B, N, M));
+        return GDM_ENOMEM;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    unsigned char* apk = ws;
+    unsigned char* bpk = apk + gdm_match_rows_bytes(B * N);
+    unsigned char* part = bpk + gdm_match_rows_bytes(M);
+    int rc = gdm_match_pack_hip(scene, B, Dd, N, precision, apk, stream);
+    if (rc) return rc;
+    rc = gdm_match_pack_hip(model, 1, Dd, M, precision, bpk, stream);
+    if (rc) return rc;
+    return gdm_match_packed_hip(apk, bpk, B * N, M, precision, best_idx, best_sim, sim, part, gdm_match_partial_bytes(B, N), stream);
 }

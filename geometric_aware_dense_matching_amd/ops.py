@@ -282,6 +282,35 @@ def match(scene, model, precision=MATCH_BF16X3, return_sim=False):
     return (best_idx, best_sim, sim) if return_sim else (best_idx, best_sim)
 
 
+def match_pack(x, precision=MATCH_BF16X3, out=None):
+    """x f32[R,128,n] (or [128,n]) channel-major -> u8[R*n, 512] normalised packed rows (stage 1 of match)."""
+    x = _dev(x, torch.float32, "x")
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    R, D, n = x.shape
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty((L.gdm_match_rows_bytes(R * n),), dtype=torch.uint8, device=x.device)
+    check(L.gdm_match_pack_hip(x.data_ptr(), R, D, n, precision, out.data_ptr(), _stream()), "gdm_match_pack_hip")
+    return out
+
+
+def match_packed(scene_rows, model_rows, B, N, M, precision=MATCH_BF16X3, return_sim=False, sim_out=None):
+    """Stage 2 of match on packed rows: the MFMA similarity + arg-max kernel (+ split merge)."""
+    L = _lib.lib()
+    dev = scene_rows.device
+    part = _workspace(L.gdm_match_partial_bytes(B, N), dev)
+    best_idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+    best_sim = torch.empty((B, N), dtype=torch.float32, device=dev)
+    sim = None
+    if return_sim:
+        sim = sim_out if sim_out is not None else torch.empty((B, N, M), dtype=torch.float32, device=dev)
+    check(L.gdm_match_packed_hip(scene_rows.data_ptr(), model_rows.data_ptr(), B * N, M, precision, best_idx.data_ptr(),
+                                 best_sim.data_ptr(), sim.data_ptr() if return_sim else None, part.data_ptr(), part.numel(),
+                                 _stream()), "gdm_match_packed_hip")
+    return (best_idx, best_sim, sim) if return_sim else (best_idx, best_sim)
+
+
 def seg_mask(seg):
     """seg f32[B,2,N] -> (mask u8[B,N] = argmax==1, count i32[B])."""
     seg = _dev(seg, torch.float32, "seg")

@@ -123,7 +123,7 @@ int gdm_att_pool_bwd_hip(const float* att, const float* feat, const float* grad_
 #define GDM_MATCH_BF16X3 0   /* split-bf16 MFMA: hi*hi + hi*lo + lo*hi, fp32 accumulate (|err| <= ~1.2e-5) */
 #define GDM_MATCH_F32    1   /* f32-input MFMA, exact fp32 products                                        */
 
-/* Workspace bytes needed by gdm_match_*_hip for the given sizes. */
+/* Workspace bytes needed by gdm_match_hip for the given sizes. */
 size_t gdm_match_workspace_bytes(int B, int N, int M);
 
 /* Fused inference matching (evaluator.py:87-93): L2-normalise each scene descriptor (over D),
@@ -133,10 +133,21 @@ size_t gdm_match_workspace_bytes(int B, int N, int M);
  *   model f32[D,M]   channel-major (end_points['mesh'][0])
  *   -> best_idx i32[B,N], best_sim f32[B,N]; sim f32[B,N,M] is also written when non-NULL
  *      (the materialised matrix of evaluator.py:91).
- * D must be 128; N % 32 == 0... (see gdm_match.hip); M % 64 == 0.                          */
+ * D must be 128; B, N, M arbitrary (an (M+1)-column padded model, geoMatch.py:117-119, works).
+ * = gdm_match_pack_hip(scene) + gdm_match_pack_hip(model) + gdm_match_packed_hip.            */
 int gdm_match_hip(const float* scene, const float* model, int B, int D, int N, int M, int precision,
                   int32_t* best_idx, float* best_sim, float* sim,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two stages separately, so that an object's model rows are packed once and reused
+ * (they are constant in eval: models/SplineCNN.py:234 takes no input).
+ * pack: x f32[R,D,n] channel-major -> R*n normalised rows of 512 bytes (gdm_match_rows_bytes(R*n)). */
+size_t gdm_match_rows_bytes(int rows);
+size_t gdm_match_partial_bytes(int B, int N);
+int gdm_match_pack_hip(const float* x, int R, int D, int n, int precision, void* rows, void* stream);
+int gdm_match_packed_hip(const void* scene_rows, const void* model_rows, int R /* B*N */, int M, int precision,
+                         int32_t* best_idx, float* best_sim, float* sim,
+                         void* partial, size_t partial_bytes, void* stream);
 
 /* seg f32[B,2,N] -> mask u8[B,N] = (argmax over the 2 classes == 1) (evaluator.py:79-83),
  * count i32[B] of selected points (zeroed inside).                                        */
