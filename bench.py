@@ -41,13 +41,33 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box
+    exposes all 256 hardware threads but grants a 1-GPU job a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return min(n, int(os.environ.get("GDM_CPU_CORES", "16")))
+
+
 def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
     """Reference CPU path as the oracle restates it (kNN leg through the compiled reference nanoflann when
     oracle/_ref travelled with the snapshot): pyramid + FFB6DEmb + heads + matching, all host cores."""
     import numpy as np
     import torch
     from oracle import knn as oknn, model_ref, ops_ref, pyramid as opyr
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     use_ref = oknn.have_ref()
     search = opyr.ref_knn_search if use_ref else None

@@ -49,6 +49,8 @@ SIGNATURES = {
     "gdm_match_pack_hip": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_match_packed_hip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "gdm_upsample_bilinear_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_upsample_bilinear_bwd_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }

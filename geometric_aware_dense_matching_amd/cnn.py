@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
@@ -87,16 +89,22 @@ class PSPModule(nn.Module):
 
     def forward(self, feats):
         h, w = feats.size(2), feats.size(3)
-        priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=True)
-                  for stage in self.stages] + [feats]
+        priors = [ops.upsample_bilinear(stage(feats), (h, w)) for stage in self.stages] + [feats]
         return self.relu(self.bottleneck(torch.cat(priors, 1)))
+
+
+class Upsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on the HIP kernel (no parameters,
+    so it keeps slot 0 of PSPUpsample.conv and the checkpoint keys conv.1/2/3 unchanged)."""
+
+    def forward(self, x):
+        return ops.upsample_bilinear(x, (x.shape[2] * 2, x.shape[3] * 2))
 
 
 class PSPUpsample(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
-        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
-                                  nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
+        self.conv = nn.Sequential(Upsample2x(), nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def forward(self, x):
         return self.conv(x)

@@ -1,0 +1,104 @@
+// Bilinear resize (align_corners=True) of NCHW fp32 feature maps, gfx950.
+//
+// Used by the image branch for nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+// (/root/reference/models/cnn/pspnet.py:38 PSPUpsample) and F.interpolate(..., size=(h,w),
+// mode='bilinear', align_corners=True) of the pyramid-pooling priors (pspnet.py:26-29).
+// PyTorch-ROCm's own kernel for this op took 2.1 ms per call at batch 16 (14.8 ms of a 36.5 ms
+// step, profiles/r01_kernel_stats_eager.csv); the op is a pure HBM stream (every output element
+// written once, every input element read ~once through L2), so it is written here as one:
+// one thread = 4 consecutive output pixels of one row (one 16-B store), source rows hit L1/L2.
+// Index / weight arithmetic is the same as ATen's (scale = (in-1)/(out-1) in fp32,
+// src = scale*dst, i0 = (int)src, lambda = src - i0, i1 = i0 + (i0 < in-1)).
+#include "gdm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, int H, int W, int OH, int OW,
+                                                                float rh, float rw, float* __restrict__ out)
+{
+    const long plane = blockIdx.z;
+    const int oy = blockIdx.y;
+    const int ox0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (ox0 >= OW) return;
+    const float sy = rh * (float)oy;
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float* r0 = in + (plane * H + y0) * (long)W;
+    const float* r1 = in + (plane * H + y1) * (long)W;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = min(ox0 + j, OW - 1);
+        const float sx = rw * (float)ox;
+        const int x0 = (int)sx;
+        const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float lx = sx - (float)x0, hx = 1.f - lx;
+        v[j] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+    }
+    float* o = out + (plane * OH + oy) * (long)OW + ox0;
+    if (ox0 + 3 < OW && (((uintptr_t)o) & 15) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int j = 0; j < 4 && ox0 + j < OW; ++j) o[j] = v[j];
+    }
+}
+
+// grad_in (zeroed by caller) += transpose of the interpolation
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ go, int H, int W, int OH, int OW,
+                                                                    float rh, float rw, float* __restrict__ gin)
+{
+    const long plane = blockIdx.z;
+    const int oy = blockIdx.y;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= OW) return;
+    const float sy = rh * (float)oy;
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float sx = rw * (float)ox;
+    const int x0 = (int)sx;
+    const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float lx = sx - (float)x0, hx = 1.f - lx;
+    const float g = go[(plane * OH + oy) * (long)OW + ox];
+    float* p0 = gin + (plane * H + y0) * (long)W;
+    float* p1 = gin + (plane * H + y1) * (long)W;
+    atomicAdd(&p0[x0], hy * hx * g);
+    atomicAdd(&p0[x1], hy * lx * g);
+    atomicAdd(&p1[x0], ly * hx * g);
+    atomicAdd(&p1[x1], ly * lx * g);
+}
+
+inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+} // namespace
+
+extern "C" int gdm_upsample_bilinear_hip(const float* in, long planes, int H, int W, int OH, int OW, float* out, void* stream)
+{
+    GDM_CHECK_ARG(in && out, "gdm_upsample_bilinear_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && planes <= 65535L * 32768 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && OH <= 65535,
+                  "gdm_upsample_bilinear_hip: bad shape planes=%ld %dx%d -> %dx%d", planes, H, W, OH, OW);
+    // planes ride blockIdx.z (<= 65535): fold the excess into repeated launches
+    const long zmax = 65535;
+    for (long p0 = 0; p0 < planes; p0 += zmax) {
+        const long np = planes - p0 < zmax ? planes - p0 : zmax;
+        dim3 grid(gdm_cdiv(gdm_cdiv(OW, 4), 256), OH, (unsigned)np);
+        hipLaunchKernelGGL(upsample_bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                           in + p0 * H * W, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), out + p0 * OH * OW);
+    }
+    return gdm_launch_status("upsample_bilinear_kernel");
+}
+
+extern "C" int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes, int H, int W, int OH, int OW, float* grad_in, void* stream)
+{
+    GDM_CHECK_ARG(grad_out && grad_in, "gdm_upsample_bilinear_bwd_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && OH <= 65535, "gdm_upsample_bilinear_bwd_hip: bad shape");
+    const long zmax = 65535;
+    for (long p0 = 0; p0 < planes; p0 += zmax) {
+        const long np = planes - p0 < zmax ? planes - p0 : zmax;
+        dim3 grid(gdm_cdiv(OW, 256), OH, (unsigned)np);
+        hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                           grad_out + p0 * OH * OW, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), grad_in + p0 * H * W);
+    }
+    return gdm_launch_status("upsample_bilinear_bwd_kernel");
+}

@@ -114,18 +114,23 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
             const float4 v = tile[p];
             const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
             if (d < dl[KMAX - 1]) {                       // strict: an equal distance has a larger index
-                dl[KMAX - 1] = d;
-                il[KMAX - 1] = tile0 + p;
+                // Branch-free sorted insertion, every slot independent of the others (no swap chain):
+                //   new[i] = old[i-1] > d ? old[i-1] : (old[i] > d ? d : old[i])
+                // '>' is strict, so the newcomer lands AFTER stored entries of equal distance (they have
+                // lower indices).  Walking i downwards reads old[i-1] before it is overwritten.
+                const int pi = tile0 + p;
+                bool gt_hi = true;                        // old[KMAX-1] > d holds (admission test)
 #pragma unroll
-                for (int i = KMAX - 1; i > 0; --i) {      // bubble up; strict '>' keeps earlier equal entries first
-                    const bool sw = dl[i - 1] > dl[i];
-                    const float dlo = sw ? dl[i] : dl[i - 1];
-                    const float dhi = sw ? dl[i - 1] : dl[i];
-                    const int ilo = sw ? il[i] : il[i - 1];
-                    const int ihi = sw ? il[i - 1] : il[i];
-                    dl[i - 1] = dlo; dl[i] = dhi;
-                    il[i - 1] = ilo; il[i] = ihi;
+                for (int i = KMAX - 1; i > 0; --i) {
+                    const bool gt_lo = dl[i - 1] > d;
+                    const float dn = gt_lo ? dl[i - 1] : (gt_hi ? d : dl[i]);
+                    const int in = gt_lo ? il[i - 1] : (gt_hi ? pi : il[i]);
+                    dl[i] = dn;
+                    il[i] = in;
+                    gt_hi = gt_lo;
                 }
+                dl[0] = gt_hi ? d : dl[0];
+                il[0] = gt_hi ? pi : il[0];
             }
         }
     }

@@ -244,6 +244,33 @@ def att_pool(att, feat):
     return _AttPool.apply(att, feat)
 
 
+class _UpsampleBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        x = _dev(x, torch.float32, "x")
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        check(_lib.lib().gdm_upsample_bilinear_hip(x.data_ptr(), B * C, H, W, OH, OW, out.data_ptr(), _stream()),
+              "gdm_upsample_bilinear_hip")
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        go = go.contiguous()
+        B, C, OH, OW = go.shape
+        H, W = ctx.hw
+        g = torch.zeros((B, C, H, W), dtype=torch.float32, device=go.device)
+        check(_lib.lib().gdm_upsample_bilinear_bwd_hip(go.data_ptr(), B * C, H, W, OH, OW, g.data_ptr(), _stream()),
+              "gdm_upsample_bilinear_bwd_hip")
+        return g, None, None
+
+
+def upsample_bilinear(x, size):
+    """x f32[B,C,H,W] -> f32[B,C,OH,OW], bilinear, align_corners=True (pspnet.py:26-29,38)."""
+    return _UpsampleBilinear.apply(x, int(size[0]), int(size[1]))
+
+
 # --------------------------------------------------------------------------------------
 # matching
 # --------------------------------------------------------------------------------------

@@ -166,6 +166,13 @@ int gdm_spline_aggregate_hip(const float* xw, const int32_t* rowptr, const int32
 int gdm_spline_aggregate_bwd_hip(const float* grad_out, const int32_t* rowptr, const int32_t* src, const float* attr,
                                  int M, int C, int kernel_size, float* grad_xw, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).
+ * in f32[planes,H,W] -> out f32[planes,OH,OW]; planes = B*C.  Backward adds into grad_in
+ * (zeroed by the caller).                                                               */
+int gdm_upsample_bilinear_hip(const float* in, long planes, int H, int W, int OH, int OW, float* out, void* stream);
+int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes, int H, int W, int OH, int OW, float* grad_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

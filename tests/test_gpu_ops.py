@@ -250,3 +250,19 @@ def test_pointops_ballquery_fps(ops):
 def test_cpu_tensor_raises(ops):
     with pytest.raises(RuntimeError):
         ops.knn_batch(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), 1)
+
+
+@pytest.mark.parametrize("B,C,H,W,OH,OW", [(2, 8, 32, 32, 64, 64), (1, 3, 1, 1, 32, 32), (2, 5, 2, 2, 32, 32), (1, 4, 3, 3, 32, 32),
+                                            (1, 4, 6, 6, 32, 32), (1, 2, 128, 128, 256, 256), (1, 3, 7, 5, 13, 18)])
+def test_upsample_bilinear_align_corners(ops, B, C, H, W, OH, OW):
+    """pspnet.py:26-29,38: the reference op is torch's own bilinear interpolate (CPU here). 1e-6 relative:
+    same index/weight arithmetic, different association of the 4-term blend."""
+    x = torch.from_numpy(np.random.RandomState(H * W).randn(B, C, H, W).astype(np.float32))
+    want = torch.nn.functional.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=True)
+    got = ops.upsample_bilinear(x.cuda(), (OH, OW)).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    a = x.clone().requires_grad_(True)
+    torch.nn.functional.interpolate(a, size=(OH, OW), mode="bilinear", align_corners=True).square().sum().backward()
+    b = x.clone().cuda().requires_grad_(True)
+    ops.upsample_bilinear(b, (OH, OW)).square().sum().backward()
+    assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-4, atol=1e-5)
