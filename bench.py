@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"])
     ap.add_argument("--cache-mesh", action="store_true", help="reuse the (input independent) mesh descriptors in eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crops", type=int, default=2)
+    ap.add_argument("--cpu-crops", type=int, default=96, help="crops in the bounded CPU sample (~10-20 s of host work)")
     return ap.parse_args()
 
 
@@ -72,7 +72,9 @@ def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
     use_ref = oknn.have_ref()
     search = opyr.ref_knn_search if use_ref else None
     t0 = time.perf_counter()
-    for i in range(n_crops):
+    nb = batch["rgb"].shape[0]
+    for j in range(n_crops):
+        i = j % nb
         pyr = opyr.build_pyramid(batch["cld_rgb_nrm"][i, :3].T.copy(), batch["dpt_xyz"][i], knn_search=search)
         inp = {k: torch.from_numpy(batch[k][i:i + 1]) for k in ("rgb", "cld_rgb_nrm", "choose")}
         inp.update({k: torch.from_numpy(v[None]) for k, v in pyr.items()})
@@ -222,7 +224,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cpu = cpu_baseline(batch, sd_cpu, ep["mesh"][0].detach().cpu(), min(args.cpu_crops, B))
+        cpu = cpu_baseline(batch, sd_cpu, ep["mesh"][0].detach().cpu(), args.cpu_crops)
 
     if rank == 0:
         line = {

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Steady-state per-kernel summary of a `rocprofv3 --kernel-trace --output-format csv` run of bench.py.
+
+bench.py's warmup runs MIOpen's find mode (hundreds of trial kernels), so whole-process --stats are
+dominated by it.  This tool cuts the trace to the TIMED steps: a step starts at its knn_kernel<1>
+launch; the window is the last `--steps` steps before the roofline loop (the first run of
+match_kernel<.., true> launches).  Usage:
+    python tools/summarize_trace.py gpurun_out/prof/*_kernel_trace.csv --steps 10 > profiles/rNN_steady.csv
+"""
+import argparse
+import collections
+import csv
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    rows = list(csv.DictReader(open(a.trace)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "knn_kernel<1>" in r["Kernel_Name"]]
+    # steps: warmup W, timed K, then one more forward before the roofline loop
+    s, e = starts[-(a.steps + 1)], starts[-1]
+    win = rows[s:e]
+    t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
+    agg = collections.OrderedDict()
+    for r in win:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        k = r["Kernel_Name"]
+        x = agg.setdefault(k, [0, 0, 1 << 62, 0])
+        x[0] += d
+        x[1] += 1
+        x[2] = min(x[2], d)
+        x[3] = max(x[3], d)
+    busy = sum(v[0] for v in agg.values())
+    w = csv.writer(sys.stdout)
+    w.writerow(["# steady-state window: %d steps, wall %.3f ms/step, GPU busy %.3f ms/step, %d kernels/step" %
+                (a.steps, (t1 - t0) / 1e6 / a.steps, busy / 1e6 / a.steps, len(win) // a.steps)])
+    w.writerow(["Name", "CallsPerStep", "MsPerStep", "AverageUs", "MinUs", "MaxUs", "PercentOfBusy"])
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        w.writerow([k, "%.1f" % (v[1] / a.steps), "%.4f" % (v[0] / 1e6 / a.steps), "%.2f" % (v[0] / v[1] / 1e3),
+                    "%.2f" % (v[2] / 1e3), "%.2f" % (v[3] / 1e3), "%.2f" % (100.0 * v[0] / busy)])
+    # roofline loop kernels (after the window)
+    tail = rows[e:]
+    for name in ("match_kernel<0, true>", "match_kernel<1, true>"):
+        ds = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail if name in r["Kernel_Name"]]
+        if ds:
+            w.writerow(["# roofline loop: %s calls=%d avg_us=%.2f min_us=%.2f" % (name, len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3)])
+
+
+if __name__ == "__main__":
+    main()
