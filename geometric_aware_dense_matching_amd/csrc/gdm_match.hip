@@ -26,6 +26,7 @@
 // Roofline: materialised form moves 4D(BN+M) + 4BNM bytes; fused form 4D(BN+M)+8BN.
 #include "gdm_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -266,6 +267,233 @@ __global__ __launch_bounds__(256) void match_kernel(const unsigned char* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// match v2: model PANEL resident in LDS, scene row-blocks streamed through registers
+// ------------------------------------------------------------------------------------------
+// One workgroup = 8 waves (2 per SIMD) owns a panel of 256 model columns (128 KiB of packed rows, the
+// whole LDS budget of a CU but for a sliver) for its lifetime and walks over row-blocks of 256 scene rows
+// (32 per wave).  After the one-time panel fill there is NO barrier and no LDS write in the loop: a wave
+// loads its 32 rows' operand (16 x 16 B per lane, straight to registers, next block prefetched), runs
+// 8 column blocks x 24 (BF16X3) MFMAs against fragments read from the swizzled panel, and stores / arg-max
+// reduces its own 32 x 256 outputs.  Tile stores of one wave overlap the MFMAs of its SIMD partner.
+// Grid: blockIdx.x -> (g = bid % G, panel = bid / G): workgroups that read the same scene rows share
+// `bid % 8`, i.e. (observed, speed only) one XCD's L2.
+constexpr int PANEL_COLS = 256;
+constexpr int PANEL_BYTES = PANEL_COLS * ROW_BYTES;     // 128 KiB
+constexpr int V2_THREADS = 512;
+constexpr int V2_ROWS = 256;                            // scene rows per workgroup iteration
+
+template <int PREC>
+__device__ __forceinline__ void load_a_rows(const unsigned char* __restrict__ apk, int row, int R, int h, u32x4 (&a)[16])
+{
+    const unsigned char* arow = apk + (long)min(row, R - 1) * ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int ch;
+        if (PREC == GDM_MATCH_BF16X3) ch = (i < 8) ? (2 * i + h) : (16 + 2 * (i - 8) + h);
+        else ch = 16 * h + i;
+        a[i] = *reinterpret_cast<const u32x4*>(arow + ch * 16);
+    }
+}
+
+template <int PREC, bool WRITE_SIM>
+__global__ __launch_bounds__(V2_THREADS) void match_panel_kernel(const unsigned char* __restrict__ apk,
+                                                                  const unsigned char* __restrict__ bpk,
+                                                                  int R, int M, int G,
+                                                                  float* __restrict__ sim,
+                                                                  float* __restrict__ pval,      // [panels, R]
+                                                                  int32_t* __restrict__ pidx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // PANEL_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lr = lane & 31;
+    const int h = lane >> 5;
+    const int g = blockIdx.x % G;
+    const int panel = blockIdx.x / G;
+    const int col0 = panel * PANEL_COLS;
+    const int ncols = min(PANEL_COLS, M - col0);
+
+    // ---- one-time panel fill: 256 columns x 32 chunks, 16 chunks per thread, coalesced 16-B loads ----
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int gi = i * V2_THREADS + tid;
+        const int col = gi >> 5, ch = gi & 31;
+        const int gc = min(col0 + col, M - 1);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(bpk + (long)gc * ROW_BYTES + ch * 16);
+        *reinterpret_cast<u32x4*>(smem + lds_chunk_off(col, ch)) = v;
+    }
+    __syncthreads();
+
+    const int nrb = (R + V2_ROWS - 1) / V2_ROWS;
+    u32x4 anext[16];
+    if (g < nrb) load_a_rows<PREC>(apk, g * V2_ROWS + wave * 32 + lr, R, h, anext);
+
+    for (int rb = g; rb < nrb; rb += G) {
+        u32x4 areg[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) areg[i] = anext[i];
+        if (rb + G < nrb) load_a_rows<PREC>(apk, (rb + G) * V2_ROWS + wave * 32 + lr, R, h, anext);
+        const int row0 = rb * V2_ROWS + wave * 32;
+
+        float best[16];
+        int bidx[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            best[i] = -INFINITY;
+            bidx[i] = 0;
+        }
+
+#pragma unroll 1
+        for (int cp = 0; cp < PANEL_COLS / 64; ++cp) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc0[i] = 0.f;
+                acc1[i] = 0.f;
+            }
+            const int c0 = cp * 64 + lr, c1 = c0 + 32;
+            if (PREC == GDM_MATCH_BF16X3) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 2 * s + h)));
+                    const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 16 + 2 * s + h)));
+                    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c1, 2 * s + h)));
+                    const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c1, 16 + 2 * s + h)));
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[s]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, areg[8 + s]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const u32x4 b0 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 16 * h + i));
+                    const u32x4 b1 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c1, 16 * h + i));
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].x), __uint_as_float(b0.x), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].x), __uint_as_float(b1.x), acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].y), __uint_as_float(b0.y), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].y), __uint_as_float(b1.y), acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].z), __uint_as_float(b0.z), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].z), __uint_as_float(b1.z), acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].w), __uint_as_float(b0.w), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(areg[i].w), __uint_as_float(b1.w), acc1, 0, 0, 0);
+                }
+            }
+            const int gc0 = col0 + c0, gc1 = col0 + c1;
+            const bool ok0 = c0 < ncols, ok1 = c1 < ncols;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v0 = acc0[reg], v1 = acc1[reg];
+                if (ok0 && v0 > best[reg]) {
+                    best[reg] = v0;
+                    bidx[reg] = gc0;
+                }
+                if (ok1 && v1 > best[reg]) {
+                    best[reg] = v1;
+                    bidx[reg] = gc1;
+                }
+                if (WRITE_SIM) {
+                    const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (grow < R) {
+                        float* o = sim + (long)grow * M;
+                        if (ok0) __builtin_nontemporal_store(v0, o + gc0);
+                        if (ok1) __builtin_nontemporal_store(v1, o + gc1);
+                    }
+                }
+            }
+        }
+
+        // ---- (max, lowest arg) across the 32 lanes of each half-wave, halving the row set every step:
+        //      after step t each lane carries 16>>(t+1) rows, so 16+8+4+2 (+2) shuffles instead of 160 ----
+        float v8[8];  int i8[8];
+        {
+            const bool up = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float sv = up ? best[i] : best[i + 8];
+                const int si = up ? bidx[i] : bidx[i + 8];
+                const float ov = __shfl_xor(sv, 1, 64);
+                const int oi = __shfl_xor(si, 1, 64);
+                const float mv = up ? best[i + 8] : best[i];
+                const int mi = up ? bidx[i + 8] : bidx[i];
+                const bool take = ov > mv || (ov == mv && oi < mi);
+                v8[i] = take ? ov : mv;
+                i8[i] = take ? oi : mi;
+            }
+        }
+        float v4[4];  int i4[4];
+        {
+            const bool up = lane & 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sv = up ? v8[i] : v8[i + 4];
+                const int si = up ? i8[i] : i8[i + 4];
+                const float ov = __shfl_xor(sv, 2, 64);
+                const int oi = __shfl_xor(si, 2, 64);
+                const float mv = up ? v8[i + 4] : v8[i];
+                const int mi = up ? i8[i + 4] : i8[i];
+                const bool take = ov > mv || (ov == mv && oi < mi);
+                v4[i] = take ? ov : mv;
+                i4[i] = take ? oi : mi;
+            }
+        }
+        float v2[2];  int i2[2];
+        {
+            const bool up = lane & 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float sv = up ? v4[i] : v4[i + 2];
+                const int si = up ? i4[i] : i4[i + 2];
+                const float ov = __shfl_xor(sv, 4, 64);
+                const int oi = __shfl_xor(si, 4, 64);
+                const float mv = up ? v4[i + 2] : v4[i];
+                const int mi = up ? i4[i + 2] : i4[i];
+                const bool take = ov > mv || (ov == mv && oi < mi);
+                v2[i] = take ? ov : mv;
+                i2[i] = take ? oi : mi;
+            }
+        }
+        float v1;  int i1;
+        {
+            const bool up = lane & 8;
+            const float sv = up ? v2[0] : v2[1];
+            const int si = up ? i2[0] : i2[1];
+            const float ov = __shfl_xor(sv, 8, 64);
+            const int oi = __shfl_xor(si, 8, 64);
+            const float mv = up ? v2[1] : v2[0];
+            const int mi = up ? i2[1] : i2[0];
+            const bool take = ov > mv || (ov == mv && oi < mi);
+            v1 = take ? ov : mv;
+            i1 = take ? oi : mi;
+        }
+        {
+            const float ov = __shfl_xor(v1, 16, 64);
+            const int oi = __shfl_xor(i1, 16, 64);
+            if (ov > v1 || (ov == v1 && oi < i1)) {
+                v1 = ov;
+                i1 = oi;
+            }
+        }
+        // lane bits 0..3 chose the upper half of the remaining row set at steps 1..4:
+        // register index reg = 8*b0 + 4*b1 + 2*b2 + b3
+        if ((lane & 16) == 0) {
+            const int reg = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+            const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (grow < R) {
+                pval[(long)panel * R + grow] = v1;
+                pidx[(long)panel * R + grow] = i1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void merge_splits_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                            int splits, int R, float* __restrict__ oval, int32_t* __restrict__ oidx)
 {
@@ -298,6 +526,14 @@ int pick_splits(int R, int M, bool write_sim)
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// 1 = tile-streaming kernel, 2 = LDS-resident panel kernel (default); GDM_MATCH_KERNEL overrides, for A/B runs.
+int match_kernel_version()
+{
+    const char* e = getenv("GDM_MATCH_KERNEL");
+    if (e && e[0] == '1') return 1;
+    return 2;
+}
 
 } // namespace
 
@@ -353,22 +589,55 @@ extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_ro
     int32_t* pidx = (int32_t*)((unsigned char*)partial + half);
 
     const bool ws_sim = sim != nullptr;
-    const int splits = pick_splits(R, M, ws_sim);
-    int cps = gdm_cdiv(gdm_cdiv(M, splits), MT_COLS) * MT_COLS;
-    const int nsplit = gdm_cdiv(M, cps);
-    dim3 grid(gdm_cdiv(R, MT_ROWS), nsplit);
-    float* ov = nsplit == 1 ? best_sim : pval;
-    int32_t* oi = nsplit == 1 ? best_idx : pidx;
-    const size_t lds = 2 * TILE_BYTES;
-#define LAUNCH(P, W) hipLaunchKernelGGL((match_kernel<P, W>), grid, dim3(256), lds, stream, apk, bpk, R, M, cps, sim, ov, oi)
-    if (precision == GDM_MATCH_BF16X3) {
-        if (ws_sim) LAUNCH(GDM_MATCH_BF16X3, true); else LAUNCH(GDM_MATCH_BF16X3, false);
+    int rc;
+    const int panels = gdm_cdiv(M, PANEL_COLS);
+    int nsplit;
+    if (match_kernel_version() == 2 && panels <= 64) {
+        // ---- v2: LDS-resident model panel, one persistent-ish workgroup per (panel, row group) ----
+        const int nrb = gdm_cdiv(R, V2_ROWS);
+        int G = 512 / panels;                                   // ~2 workgroups' worth of work per CU queue
+        if (G < 1) G = 1;
+        if (G > nrb) G = nrb;
+        if (G >= 8) G &= ~7;                                    // keep same-rows workgroups on one bid%8 class
+        nsplit = panels;
+        dim3 grid(panels * G);
+        float* ov = nsplit == 1 ? best_sim : pval;
+        int32_t* oi = nsplit == 1 ? best_idx : pidx;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            attr_set = true;
+        }
+#define LAUNCH2(P, W) hipLaunchKernelGGL((match_panel_kernel<P, W>), grid, dim3(V2_THREADS), PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi)
+        if (precision == GDM_MATCH_BF16X3) {
+            if (ws_sim) LAUNCH2(GDM_MATCH_BF16X3, true); else LAUNCH2(GDM_MATCH_BF16X3, false);
+        } else {
+            if (ws_sim) LAUNCH2(GDM_MATCH_F32, true); else LAUNCH2(GDM_MATCH_F32, false);
+        }
+#undef LAUNCH2
+        rc = gdm_launch_status("match_panel_kernel");
+        if (rc) return rc;
     } else {
-        if (ws_sim) LAUNCH(GDM_MATCH_F32, true); else LAUNCH(GDM_MATCH_F32, false);
-    }
+        const int splits = pick_splits(R, M, ws_sim);
+        int cps = gdm_cdiv(gdm_cdiv(M, splits), MT_COLS) * MT_COLS;
+        nsplit = gdm_cdiv(M, cps);
+        dim3 grid(gdm_cdiv(R, MT_ROWS), nsplit);
+        float* ov = nsplit == 1 ? best_sim : pval;
+        int32_t* oi = nsplit == 1 ? best_idx : pidx;
+        const size_t lds = 2 * TILE_BYTES;
+#define LAUNCH(P, W) hipLaunchKernelGGL((match_kernel<P, W>), grid, dim3(256), lds, stream, apk, bpk, R, M, cps, sim, ov, oi)
+        if (precision == GDM_MATCH_BF16X3) {
+            if (ws_sim) LAUNCH(GDM_MATCH_BF16X3, true); else LAUNCH(GDM_MATCH_BF16X3, false);
+        } else {
+            if (ws_sim) LAUNCH(GDM_MATCH_F32, true); else LAUNCH(GDM_MATCH_F32, false);
+        }
 #undef LAUNCH
-    int rc = gdm_launch_status("match_kernel");
-    if (rc) return rc;
+        rc = gdm_launch_status("match_kernel");
+        if (rc) return rc;
+    }
     if (nsplit > 1) {
         hipLaunchKernelGGL(merge_splits_kernel, dim3(gdm_cdiv(R, 256)), dim3(256), 0, stream, pval, pidx, nsplit, R, best_sim, best_idx);
         rc = gdm_launch_status("merge_splits_kernel");
