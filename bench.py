@@ -187,6 +187,7 @@ def main():
                       "frac": round(mfma_flops / (match_ms * 1e-3) / 1e12 / peak_tf, 4),
                       "algorithmic_tflops": round(flops / (match_ms * 1e-3) / 1e12, 2),
                       "avg_ms": round(match_ms, 4), "traffic": None}
+    _ = fused_bytes
     with torch.no_grad():
         ep_rgbd, ep_mesh = None, None
         d = dict(inputs)
@@ -208,11 +209,15 @@ def main():
         torch.cuda.synchronize()
         mat_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         del sim
+    # PMC traffic comes from separate rocprofv3 --pmc passes (profiles/match_traffic.json), valid for the
+    # headline shape only
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "match_traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and (B, N, M, args.precision) == (16, 2048, 8192, "bf16x3"):
         try:
-            traffic = json.load(open(tfile)).get("materialised_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("materialised_bytes_per_launch")
+            roofline_fused["traffic"] = tj.get("fused_kernel", {}).get("bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"kernel": "match_kernel<materialised sim> (N x 8192 descriptor-distance kernel)", "bound": "hbm",
