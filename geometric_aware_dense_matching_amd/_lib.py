@@ -51,6 +51,9 @@ SIGNATURES = {
     "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gdm_upsample_bilinear_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
     "gdm_upsample_bilinear_bwd_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_topk_rows_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp]),
+    "gdm_edge_feature_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_edge_feature_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }

@@ -244,6 +244,48 @@ def att_pool(att, feat):
     return _AttPool.apply(att, feat)
 
 
+def topk_rows(score, k, return_values=False):
+    """score f32[..., n] -> idx i32[..., k] of the k largest per row (ties: lower column first)
+    (dgcnn.py:26 `pairwise_distance.topk(k=k, dim=-1)[1]`)."""
+    score = _dev(score, torch.float32, "score")
+    n = score.shape[-1]
+    rows = score.numel() // n
+    idx = torch.empty(score.shape[:-1] + (k,), dtype=torch.int32, device=score.device)
+    val = torch.empty(score.shape[:-1] + (k,), dtype=torch.float32, device=score.device) if return_values else None
+    check(_lib.lib().gdm_topk_rows_hip(score.data_ptr(), rows, n, k, idx.data_ptr(), val.data_ptr() if return_values else None,
+                                       _stream()), "gdm_topk_rows_hip")
+    return (idx, val) if return_values else idx
+
+
+class _EdgeFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = _dev(x, torch.float32, "x")
+        B, C, n = x.shape
+        K = idx.shape[2]
+        out = torch.empty((B, 2 * C, n, K), dtype=torch.float32, device=x.device)
+        check(_lib.lib().gdm_edge_feature_hip(x.data_ptr(), idx.data_ptr(), B, C, n, K, out.data_ptr(), _stream()),
+              "gdm_edge_feature_hip")
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (idx,) = ctx.saved_tensors
+        go = go.contiguous()
+        B, C2, n, K = go.shape
+        g = torch.zeros((B, C2 // 2, n), dtype=torch.float32, device=go.device)
+        check(_lib.lib().gdm_edge_feature_bwd_hip(go.data_ptr(), idx.data_ptr(), B, C2 // 2, n, K, g.data_ptr(), _stream()),
+              "gdm_edge_feature_bwd_hip")
+        return g, None
+
+
+def edge_feature(x, idx):
+    """x f32[B,C,n], idx int[B,n,K] -> f32[B,2C,n,K] = cat(x_j - x_i, x_i) (dgcnn.py:30-56 get_graph_feature)."""
+    idx = _idx32(idx, "idx")
+    return _EdgeFeature.apply(x, idx)
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

@@ -150,7 +150,7 @@ class Trainer:
                 self.model.train()
                 out, _ = model_fn_dec(self.model, batch, self.device)
                 loss = out["loss"]
-                vals = (loss.item(), out["seg_loss"].item(), float(out["match_loss"]))
+                vals = (loss.item(), out["seg_loss"].item(), float(out["match_loss"].detach()))
                 sums += vals
                 self.history.append(vals)
                 if (it + 1) % self.log_every == 0 and self.local_rank == 0:

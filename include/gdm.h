@@ -173,6 +173,15 @@ int gdm_spline_aggregate_bwd_hip(const float* grad_out, const int32_t* rowptr, c
 int gdm_upsample_bilinear_hip(const float* in, long planes, int H, int W, int OH, int OW, float* out, void* stream);
 int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes, int H, int W, int OH, int OW, float* grad_in, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * DGCNN variant (models/dgcnn.py, models/geoMatch_DGCNN.py).
+ * top-k per row of a dense score matrix (dgcnn.py:21-27 `pairwise_distance.topk(k)`): score f32[rows,n]
+ * -> idx i32[rows,K] (descending score, ties by ascending column), val f32[rows,K] or NULL.  K <= 32.
+ * edge feature (dgcnn.py:30-56): x f32[B,C,n], idx i32[B,n,K] -> out f32[B,2C,n,K] = cat(x_j - x_i, x_i). */
+int gdm_topk_rows_hip(const float* score, long rows, int n, int K, int32_t* idx, float* val, void* stream);
+int gdm_edge_feature_hip(const float* x, const int32_t* idx, int B, int C, int n, int K, float* out, void* stream);
+int gdm_edge_feature_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int K, float* grad_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

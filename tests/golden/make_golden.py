@@ -258,6 +258,44 @@ def main():
     np.savez_compressed(os.path.join(HERE, "matching.npz"), statements=np.array(stmts),
                         cls_msk=env["cls_msk"].numpy(), max_th=env["max_th"].numpy(),
                         obj_pts_idx=env["obj_pts_idx"].numpy(), sim_corner=env["obj_pts_sim"][:64, :64].numpy())
+
+    # ------------------------------------------------------------------ DGCNN variant (models/dgcnn.py, geoMatch_DGCNN.py)
+    import models.dgcnn as DG
+    src = open(os.path.join(REF, "models", "dgcnn.py")).read().split("\n")
+    a0 = next(i for i, l in enumerate(src) if l.startswith("def get_graph_feature"))
+    a1 = next(i for i in range(a0 + 1, len(src)) if src[i].startswith("class "))
+    patched = "\n".join(src[a0:a1]).replace("torch.device('cuda')", "torch.device('cpu')")   # dgcnn.py:39 hard-codes cuda
+    exec(patched, DG.__dict__)
+    import models.geoMatch_DGCNN as GMD
+    Md = 384
+    mp = synthetic.make_model_points(1, Md)
+    os.makedirs("/tmp/gdm_golden_kps", exist_ok=True)
+    np.save("/tmp/gdm_golden_kps/obj_000001_fps.npy", mp)
+    _npfloat = getattr(np, "float", None)
+    np.float = float                                                   # dgcnn.py:190 uses the removed np.float alias
+    dcfg = dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, model_pth="/tmp/gdm_golden_kps", n_mesh_node=Md)
+    dmodel = GMD.GeoMatch(dcfg, 1)
+    if _npfloat is None:
+        del np.float
+    dmodel.model_emb.k = 20
+    dsd = synthetic.synthetic_state_dict({k: v for k, v in dmodel.state_dict().items() if k != "model_emb.mesh"}, seed=9)
+    dmodel.load_state_dict(dsd, strict=False)
+    dmodel.eval()
+    dkeys = {k: list(v.shape) for k, v in dmodel.state_dict().items()}
+    json.dump(dkeys, open(os.path.join(HERE, "dgcnn_state.json"), "w"), indent=0, sort_keys=True)
+    dbatch = synthetic.make_batch(seed=8, batch=2, n_points=512)
+    dx = torch.from_numpy(dbatch["cld_rgb_nrm"])
+    with torch.no_grad():
+        dep = dmodel(dict(cld_rgb_nrm=dx))
+        demb = dmodel.pcd_emb(dx)
+        idx3 = DG.knn(dx[:, :3], 16)
+    dg = dict(mesh_buffer=dmodel.model_emb.mesh.numpy(), knn_xyz=idx3.numpy().astype(np.int32))
+    for name, t in (("seg", dep["seg"]), ("rgbd", dep["rgbd"]), ("emb", demb), ("mesh", dep["mesh"])):
+        pos, val = sample_entries(t, 4096, seed=len(name) + 40)
+        dg[name + "_pos"], dg[name + "_val"] = pos, val
+        dg[name + "_norm"] = np.float64(t.double().norm().item())
+        dg[name + "_shape"] = np.array(t.shape)
+    np.savez_compressed(os.path.join(HERE, "dgcnn_eval.npz"), **dg)
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         print("  %-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -205,3 +205,43 @@ def test_end_to_end_vs_oracle_c1(golden_model):
     assert (res["best_sim"][0].cpu() - wv).abs().max() < 1e-4
     at = ws.gather(1, res["best_idx"][0].cpu().long().unsqueeze(1)).squeeze(1)
     assert ((wv - at) < 1e-4).all()
+
+
+def test_dgcnn_variant_vs_reference_golden_and_oracle():
+    """geoMatch_DGCNN (BASELINE config 4): product on the GPU vs the real reference's outputs.  The dynamic
+    graph comes from fp32 GEMM distances, so a few near-tie neighbours may differ (see test_oracle_model)."""
+    from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
+    g = np.load(os.path.join(G, "dgcnn_eval.npz"))
+    keys = json.load(open(os.path.join(G, "dgcnn_state.json")))
+    model = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=384), 1,
+                          model_points=synthetic.make_model_points(1, 384))
+    model.model_emb.k = 20
+    sd = synthetic.synthetic_state_dict({k: torch.zeros(v) for k, v in keys.items() if k != "model_emb.mesh"}, seed=9)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda().eval()
+    x = torch.from_numpy(synthetic.make_batch(seed=8, batch=2, n_points=512)["cld_rgb_nrm"]).cuda()
+    with torch.no_grad():
+        ep = model(dict(cld_rgb_nrm=x))
+        emb = model.pcd_emb(x)
+    from geometric_aware_dense_matching_amd import dgcnn
+    idx3 = dgcnn.knn(x[:, :3].contiguous(), 16).cpu().numpy()
+    assert (np.sort(idx3, axis=-1) == np.sort(g["knn_xyz"], axis=-1)).mean() > 0.995
+    for name, t in (("emb", emb), ("rgbd", ep["rgbd"]), ("seg", ep["seg"]), ("mesh", ep["mesh"])):
+        t = t.float().cpu()
+        assert list(t.shape) == list(g[name + "_shape"])
+        got = t.reshape(-1)[torch.from_numpy(g[name + "_pos"])].numpy()
+        scale = max(1.0, float(np.abs(g[name + "_val"]).max()))
+        assert (np.abs(got - g[name + "_val"]) < 5e-4 * scale).mean() > 0.99, name
+        assert abs(t.double().norm().item() - float(g[name + "_norm"])) < 2e-3 * float(g[name + "_norm"])
+    # training mode runs end to end (losses finite, gradients reach both trunks)
+    model.train()
+    rs = np.random.RandomState(0)
+    inp = dict(cld_rgb_nrm=x, labels=torch.from_numpy((rs.rand(2, 512) < 0.5).astype(np.int64)).cuda(),
+               origin_labels=torch.from_numpy((rs.rand(2, 512) < 0.5).astype(np.int64)).cuda(),
+               match_idx=torch.from_numpy(rs.randint(0, 385, size=(2, 512)).astype(np.int64)).cuda(),
+               visible_flag=torch.from_numpy((rs.rand(2, 384) < 0.6).astype(np.float32)).cuda(),
+               RT=torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.9]], dtype=torch.float32).repeat(2, 1, 1).cuda())
+    out = model(inp)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]) and model.pcd_emb.conv1[0].weight.grad.abs().sum() > 0
+    assert model.model_emb.conv1[0].weight.grad.abs().sum() > 0

@@ -266,3 +266,36 @@ def test_upsample_bilinear_align_corners(ops, B, C, H, W, OH, OW):
     b = x.clone().cuda().requires_grad_(True)
     ops.upsample_bilinear(b, (OH, OW)).square().sum().backward()
     assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,n,k", [(64, 2048, 16), (7, 8192, 20), (5, 100, 4), (3, 33, 32)])
+def test_topk_rows(ops, rows, n, k):
+    rs = np.random.RandomState(rows + n)
+    s = torch.from_numpy(rs.randn(rows, n).astype(np.float32))
+    s[0, : n // 2] = s[0, n // 2: 2 * (n // 2)]            # exact ties: lower column first
+    idx, val = ops.topk_rows(s.cuda(), k, return_values=True)
+    wv, _ = torch.topk(s, k, dim=-1)
+    assert torch.equal(val.cpu(), wv)                       # values: bit-exact, descending
+    got = idx.cpu().long()
+    assert torch.equal(s.gather(1, got), wv)
+    order = np.lexsort((np.arange(n)[None, :].repeat(rows, 0), -s.numpy()), axis=1)[:, :k]
+    assert np.array_equal(got.numpy(), order)
+
+
+def test_edge_feature_and_backward(ops):
+    from oracle import dgcnn_ref
+    rs = np.random.RandomState(3)
+    B, C, n, k = 2, 9, 200, 16
+    x = torch.from_numpy(rs.randn(B, C, n).astype(np.float32))
+    want = dgcnn_ref.get_graph_feature(x, k, dim9=True)
+    idx, _ = dgcnn_ref.knn(x[:, :3], k)
+    got = ops.edge_feature(x.cuda(), idx.cuda())
+    assert torch.equal(got.cpu(), want)
+    a = x.clone().requires_grad_(True)
+    w = torch.from_numpy(rs.randn(*want.shape).astype(np.float32))
+    xt = a.transpose(2, 1)
+    f = xt.reshape(B * n, C)[(idx + torch.arange(B).view(-1, 1, 1) * n).view(-1)].view(B, n, k, C)
+    (torch.cat((f - xt.unsqueeze(2), xt.unsqueeze(2).expand(B, n, k, C)), dim=3).permute(0, 3, 1, 2) * w).sum().backward()
+    b = x.clone().cuda().requires_grad_(True)
+    (ops.edge_feature(b, idx.cuda()) * w.cuda()).sum().backward()
+    assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-4, atol=1e-4)
