@@ -116,6 +116,7 @@ def synthetic_state_dict(template, seed=0):
     `template`: mapping name -> tensor/array (only shapes and dtypes are read).
     BatchNorm running_var is kept positive, weights are scaled ~ kaiming so activations stay O(1)."""
     import hashlib
+    import re
     import torch
     out = {}
     for name, t in template.items():
@@ -123,6 +124,9 @@ def synthetic_state_dict(template, seed=0):
         # `final` is ONE module registered under two names (models/ffb6d.py:79-80): a real checkpoint
         # holds identical tensors under both, so both names must hash alike.
         canon = name.replace("cnn_up_stages.2.0.", "cnn_up_stages.3.1.")
+        # DGCNN registers each BatchNorm twice: as `bnN` and inside `convN = Sequential(conv, bnN, act)`
+        # (models/dgcnn.py:67-80), i.e. keys bnN.* and convN.1.* alias one tensor.
+        canon = re.sub(r"(^|\.)conv(\d)\.1\.", r"\1bn\2.", canon)
         h = int.from_bytes(hashlib.sha256((canon + "|%d" % seed).encode()).digest()[:4], "little")
         rs = np.random.RandomState(h)
         if name.endswith("num_batches_tracked"):

@@ -106,7 +106,7 @@ def test_forward_accepts_int64_indices_like_train_lm(golden_model):
         a = model(dict(d))["rgbd"]
         d64 = {k: (v.long() if v.dtype == torch.int32 else v) for k, v in d.items()}
         b = model(d64)["rgbd"]
-    assert torch.equal(a, b)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)        # MIOpen may pick atomically-reduced conv kernels: not bitwise
 
 
 def test_mesh_branch_vs_oracle(golden_model):
