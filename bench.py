@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"])
     ap.add_argument("--cache-mesh", action="store_true", help="reuse the (input independent) mesh descriptors in eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (default). gloo only to rehearse the multi-process path on a 1-GPU box "
+                         "(all ranks then share cuda:0 via GDM_FORCE_DEVICE=0)")
     ap.add_argument("--cpu-crops", type=int, default=96, help="crops in the bounded CPU sample (~10-20 s of host work)")
     return ap.parse_args()
 
@@ -103,10 +106,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    if "GDM_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["GDM_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv kernels during warmup
 
     B, N, M = args.batch, args.npoints, args.mesh
@@ -167,7 +175,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
