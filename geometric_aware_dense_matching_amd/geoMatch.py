@@ -42,6 +42,7 @@ class GeoMatch(nn.Module):
         self.normalize_feature_layer = pt_conv1d(self.feat_dim, self.feat_dim, bn=True)
 
         self.cache_mesh_in_eval = cache_mesh_in_eval
+        self.fused_loss = True          # False: the reference's per-item loop in plain torch (kept for A/B checks)
         self._mesh_cache = None
 
     # ------------------------------------------------------------------ training matching (geoMatch.py:55-157)
@@ -72,7 +73,35 @@ class GeoMatch(nn.Module):
         p_n_mask[cld_idx, selected_idx] = True
         return self.circle_loss(similarity, p_n_mask, 0.2)
 
+    def pointwise_feature_matching_fused(self, rgbd_feature, mesh_feature, x):
+        """Same value and gradients as pointwise_feature_matching (non-symmetric objects), batched:
+        one GEMM for all selected points of the batch, then the fused circle-loss rows kernel
+        (ops.circle_rows); no per-item Python loop over [n_i, M+1] temporaries."""
+        from . import ops
+        B = rgbd_feature.shape[0]
+        mesh = mesh_feature[0]
+        M = mesh.shape[1]
+        padding = -torch.ones((self.feat_dim, 1), dtype=torch.float32, device=mesh.device)
+        mesh_padded = F.normalize(torch.cat([mesh, padding], dim=1), p=2, dim=0)
+        labels = x["labels"]
+        sel = labels == 1                                          # [B,N]
+        counts = sel.sum(dim=1)
+        item_ok = counts >= 3                                      # geoMatch.py:126-127
+        sel = sel & item_ok.unsqueeze(1)
+        bi, pi = torch.nonzero(sel, as_tuple=True)                 # row-major: item, then point order
+        if bi.numel() == 0:
+            return torch.zeros((), device=mesh.device)
+        rows = F.normalize(rgbd_feature.transpose(1, 2)[bi, pi], p=2, dim=1)      # [R,128]
+        sim = torch.matmul(rows, mesh_padded)                      # [R, M+1]
+        match = x["match_idx"][bi, pi]
+        lrow = ops.circle_rows(sim, match, bi, self.model_emb.xyz.contiguous(), x["visible_flag"], self.positive_r, 16.0, 0.2)
+        per_item = torch.zeros(B, dtype=torch.float32, device=mesh.device).index_add_(0, bi, lrow)
+        per_item = per_item[item_ok] / counts[item_ok].to(torch.float32)
+        return per_item.mean()
+
     def pointwise_feature_matching(self, rgbd_feature, mesh_feature, x):
+        if self.model_emb.sys_corr_idx is None and rgbd_feature.is_cuda and self.fused_loss:
+            return self.pointwise_feature_matching_fused(rgbd_feature, mesh_feature, x)
         match_loss = []
         batch = rgbd_feature.shape[0]
         rgbd_feature = rgbd_feature.transpose(1, 2)

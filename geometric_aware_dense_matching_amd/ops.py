@@ -286,6 +286,46 @@ def edge_feature(x, idx):
     return _EdgeFeature.apply(x, idx)
 
 
+class _CircleRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sim, match, item, xyz, vis, radius, gamma, m):
+        sim = _dev(sim, torch.float32, "sim")
+        R, Mp = sim.shape
+        lse_p = torch.empty(R, dtype=torch.float32, device=sim.device)
+        lse_n = torch.empty_like(lse_p)
+        loss = torch.empty_like(lse_p)
+        check(_lib.lib().gdm_circle_rows_fwd_hip(sim.data_ptr(), R, Mp, match.data_ptr(), item.data_ptr(), xyz.data_ptr(),
+                                                 vis.data_ptr(), radius, gamma, m, lse_p.data_ptr(), lse_n.data_ptr(),
+                                                 loss.data_ptr(), _stream()), "gdm_circle_rows_fwd_hip")
+        ctx.save_for_backward(sim, match, item, xyz, vis, lse_p, lse_n)
+        ctx.consts = (radius, gamma, m)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        sim, match, item, xyz, vis, lse_p, lse_n = ctx.saved_tensors
+        radius, gamma, m = ctx.consts
+        g = g.contiguous()
+        R, Mp = sim.shape
+        dsim = torch.empty_like(sim)
+        check(_lib.lib().gdm_circle_rows_bwd_hip(sim.data_ptr(), R, Mp, match.data_ptr(), item.data_ptr(), xyz.data_ptr(),
+                                                 vis.data_ptr(), radius, gamma, m, lse_p.data_ptr(), lse_n.data_ptr(),
+                                                 g.data_ptr(), dsim.data_ptr(), _stream()), "gdm_circle_rows_bwd_hip")
+        return dsim, None, None, None, None, None, None, None
+
+
+def circle_rows(sim, match, item, xyz, vis, radius, gamma=16.0, m=0.2):
+    """Per-row circle loss with the on-the-fly positive mask (geoMatch.py:55-83 + loss.py:470-494).
+    sim f32[R,M+1], match int[R] (M = none), item int[R], xyz f32[M,3], vis (any dtype, nonzero = visible)[B,M] -> f32[R]."""
+    match = _idx32(match, "match")
+    item = _idx32(item, "item")
+    xyz = _dev(xyz, torch.float32, "xyz")
+    if not vis.is_cuda:
+        raise RuntimeError("vis must be a CUDA (HIP) tensor: the geoMatch ops have no CPU fallback")
+    vis8 = (vis != 0).to(torch.uint8).contiguous()
+    return _CircleRows.apply(sim, match, item, xyz, vis8, float(radius), float(gamma), float(m))
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

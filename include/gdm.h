@@ -182,6 +182,20 @@ int gdm_topk_rows_hip(const float* score, long rows, int n, int K, int32_t* idx,
 int gdm_edge_feature_hip(const float* x, const int32_t* idx, int B, int C, int n, int K, float* out, void* stream);
 int gdm_edge_feature_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int K, float* grad_x, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Fused circle loss rows for the training matching (models/geoMatch.py:55-83 matching_loss,
+ * models/loss.py:441-494 CircleLoss): positive mask evaluated on the fly, two masked LSEs online.
+ * sim f32[R, M+1] (all selected points of the batch, concatenated), match i32[R] (ground-truth vertex, M = none),
+ * item i32[R] (batch item of the row), xyz f32[M,3], vis u8[B,M], radius / gamma / m scalars
+ * -> lse_p, lse_n, loss f32[R] (loss = softplus(lse_p + lse_n)).
+ * Backward: grad_rows f32[R] -> dsim f32[R, M+1].                                             */
+int gdm_circle_rows_fwd_hip(const float* sim, int R, int Mp, const int32_t* match, const int32_t* item,
+                            const float* xyz, const uint8_t* vis, float radius, float gamma, float m,
+                            float* lse_p, float* lse_n, float* loss, void* stream);
+int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* match, const int32_t* item,
+                            const float* xyz, const uint8_t* vis, float radius, float gamma, float m,
+                            const float* lse_p, const float* lse_n, const float* grad_rows, float* dsim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

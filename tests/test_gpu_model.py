@@ -245,3 +245,57 @@ def test_dgcnn_variant_vs_reference_golden_and_oracle():
     out["loss"].backward()
     assert torch.isfinite(out["loss"]) and model.pcd_emb.conv1[0].weight.grad.abs().sum() > 0
     assert model.model_emb.conv1[0].weight.grad.abs().sum() > 0
+
+
+def test_fused_circle_loss_equals_reference_loop(golden_model):
+    """ops.circle_rows (on-the-fly mask + online masked LSE) vs the reference-shaped per-item loop (plain torch):
+    same loss and same gradients w.r.t. both descriptor sets; also per-row against the oracle's CircleLoss."""
+    from geometric_aware_dense_matching_amd import ops
+    model, _ = golden_model
+    rs = np.random.RandomState(5)
+    B, N, M = 3, 300, 512
+    dev = torch.device("cuda")
+    x = dict(labels=torch.from_numpy((rs.rand(B, N) < 0.5).astype(np.int64)).to(dev),
+             match_idx=torch.from_numpy(rs.randint(0, M + 1, size=(B, N)).astype(np.int64)).to(dev),
+             visible_flag=torch.from_numpy((rs.rand(B, M) < 0.5).astype(np.uint8)).to(dev), RT=torch.zeros(B, 3, 4, device=dev))
+    x["labels"][2] = 0                                      # an item with < 3 selected points is skipped
+    x["labels"][2, :2] = 1
+    saved = model.positive_r
+    model.positive_r = 0.02
+    try:
+        outs = []
+        for fused in (True, False):
+            model.fused_loss = fused
+            rgbd = torch.from_numpy(rs.randn(B, 128, N).astype(np.float32)).to(dev)
+            mesh = torch.from_numpy(rs.randn(1, 128, M).astype(np.float32)).to(dev)
+            if outs:
+                rgbd, mesh = outs[0][3].detach().clone(), outs[0][4].detach().clone()
+            rgbd.requires_grad_(True)
+            mesh.requires_grad_(True)
+            loss = model.pointwise_feature_matching(rgbd, mesh, x)
+            loss.backward()
+            outs.append((loss.item(), rgbd.grad.clone(), mesh.grad.clone(), rgbd, mesh))
+        assert abs(outs[0][0] - outs[1][0]) < 1e-5 * max(1.0, abs(outs[1][0]))
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-3, atol=1e-7)
+        assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-7)
+    finally:
+        model.fused_loss, model.positive_r = True, saved
+    # per-row values vs the oracle-side CircleLoss on an explicit mask
+    from geometric_aware_dense_matching_amd.loss import CircleLoss
+    R, Mp = 40, 101
+    sim = torch.from_numpy((rs.rand(R, Mp) * 2 - 1).astype(np.float32))
+    xyz = torch.from_numpy(rs.rand(Mp - 1, 3).astype(np.float32))
+    match = torch.from_numpy(rs.randint(0, Mp, size=R).astype(np.int64))
+    vis = torch.from_numpy((rs.rand(1, Mp - 1) < 0.7).astype(np.uint8))
+    r = 0.35
+    d = torch.sqrt(((xyz[match.clamp(max=Mp - 2)].unsqueeze(1) - xyz.unsqueeze(0)) ** 2).sum(2) + 1e-7)
+    mask = (d < r) & vis.bool() & (match != Mp - 1).unsqueeze(1)
+    mask = torch.cat([mask, (match == Mp - 1).unsqueeze(1)], dim=1)
+    got = ops.circle_rows(sim.cuda(), match.cuda(), torch.zeros(R, dtype=torch.int64).cuda(), xyz.cuda(), vis.cuda(), r).cpu()
+    cl = CircleLoss(16)
+    for i in range(R):
+        if mask[i].any():
+            want = cl(sim[i:i + 1], mask[i:i + 1], 0.2).item()
+            assert abs(got[i].item() - want) < 1e-4 * max(1.0, abs(want)), i
+        else:
+            assert got[i].item() == 0.0                   # empty positive set: softplus(-inf) = 0 (the reference's gradient is NaN there)
