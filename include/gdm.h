@@ -196,6 +196,14 @@ int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* matc
                             const float* xyz, const uint8_t* vis, float radius, float gamma, float m,
                             const float* lse_p, const float* lse_n, const float* grad_rows, float* dsim, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Pose solve statistics (evaluator.py:85-100 + utils/pvn3d_eval_utils_kpls.py:43-77 best_fit_transform).
+ * Per crop, over the points with mask != 0: out[b] = { n, sum A (3), sum B (3), sum A_i B_j (9, row-major) } as f64,
+ * A = model_xyz[best_idx] (f32[M,3]), B = scene point.  Scene xyz addressing: element (b, i, c) at
+ * scene_xyz[b*scene_bstride + i*pt_stride + c*ch_stride] (so both [B,N,3] and the first rows of cld_rgb_nrm [B,9,N] work). */
+int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stride, int ch_stride, const float* model_xyz,
+                         const int32_t* best_idx, const uint8_t* mask, int B, int N, int M, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

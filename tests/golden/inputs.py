@@ -38,3 +38,27 @@ def block_inputs(B=2, n=128, K=16, seed=7):
         feat8=rs.randn(B, 8, n, 1).astype(np.float32),
         fset=rs.randn(B, 32, n, K).astype(np.float32),
     )
+
+
+def pose_inputs(B=3, N=600, M=500, seed=17):
+    """Correspondences with a known rigid motion + noise + outliers; one crop with too few points."""
+    rs = np.random.RandomState(seed)
+    model = (rs.rand(M, 3).astype(np.float32) - 0.5) * 0.2
+    idx = rs.randint(0, M, size=(B, N)).astype(np.int32)
+    mask = (rs.rand(B, N) < 0.6).astype(np.uint8)
+    mask[2] = 0
+    mask[2, :3] = 1
+    cld = np.zeros((B, 9, N), np.float32)
+    RT = np.zeros((B, 3, 4), np.float32)
+    for b in range(B):
+        q, _ = np.linalg.qr(rs.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        t = np.array([0.05 * b, -0.02, 0.9], np.float32)
+        RT[b, :, :3], RT[b, :, 3] = q, t
+        pts = model[idx[b]] @ q.T.astype(np.float32) + t + 0.002 * rs.randn(N, 3).astype(np.float32)
+        out = rs.rand(N) < 0.1
+        pts[out] += 0.05 * rs.randn(int(out.sum()), 3).astype(np.float32)
+        cld[b, :3] = pts.T
+        cld[b, 3:] = rs.rand(6, N)
+    return dict(model=model, idx=idx, mask=mask, cld=cld, RT=RT)

@@ -296,6 +296,34 @@ def main():
         dg[name + "_norm"] = np.float64(t.double().norm().item())
         dg[name + "_shape"] = np.array(t.shape)
     np.savez_compressed(os.path.join(HERE, "dgcnn_eval.npz"), **dg)
+
+    # ------------------------------------------------------------------ pose solve + ADD/ADI, from the reference's own text
+    def grab(path, name, until="def "):
+        src = open(os.path.join(REF, path)).read().split("\n")
+        a0 = next(i for i, l in enumerate(src) if l.startswith("def " + name))
+        a1 = next(i for i in range(a0 + 1, len(src)) if src[i].startswith(until))
+        return "\n".join(src[a0:a1])
+    from scipy import spatial as _spatial
+    env = dict(np=np, spatial=_spatial)
+    exec(grab("utils/pvn3d_eval_utils_kpls.py", "best_fit_transform"), env)
+    exec(grab("lib/pysixd/misc.py", "transform_pts_Rt"), env)
+    misc_ns = types.SimpleNamespace(transform_pts_Rt=env["transform_pts_Rt"])
+    env["misc"] = misc_ns
+    exec(grab("lib/pysixd/pose_error.py", "add").replace("transform_pts_Rt(", "misc.transform_pts_Rt("), env)
+    exec(grab("lib/pysixd/pose_error.py", "adi").replace("transform_pts_Rt(", "misc.transform_pts_Rt("), env)
+    pi = gin.pose_inputs()
+    poses, adds, adis = [], [], []
+    for b in range(pi["idx"].shape[0]):
+        sel = pi["mask"][b].astype(bool)
+        if sel.sum() < 5:
+            T = np.eye(4)[:3].copy()
+            T[2, 3] = -1000
+        else:
+            T = env["best_fit_transform"](pi["model"][pi["idx"][b][sel]], pi["cld"][b, :3].T[sel])
+        poses.append(T)
+        adds.append(env["add"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
+        adis.append(env["adi"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
+    np.savez_compressed(os.path.join(HERE, "pose.npz"), RT=np.stack(poses), add=np.array(adds), adi=np.array(adis))
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         print("  %-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -114,3 +114,18 @@ def test_dgcnn_variant_matches_reference_golden():
         scale = max(1.0, float(np.abs(g[name + "_val"]).max()))
         assert _robust_close(got, g[name + "_val"], 2e-4 * scale), name
         assert abs(t.double().norm().item() - float(g[name + "_norm"])) < 1e-3 * float(g[name + "_norm"])
+
+
+def test_pose_solve_and_errors_match_reference_text():
+    from oracle import pose_ref
+    g = np.load(os.path.join(G, "pose.npz"))
+    pi = gin.pose_inputs()
+    for b in range(pi["idx"].shape[0]):
+        sel = pi["mask"][b].astype(bool)
+        if sel.sum() < 5:
+            continue
+        T = pose_ref.best_fit_transform(pi["model"][pi["idx"][b][sel]], pi["cld"][b, :3].T[sel])
+        assert np.array_equal(T, g["RT"][b])
+        Rg, tg, pts = pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)
+        assert pose_ref.add(T[:, :3], T[:, 3], Rg, tg, pts) == g["add"][b]
+        assert abs(pose_ref.adi(T[:, :3], T[:, 3], Rg, tg, pts) - g["adi"][b]) < 1e-12
