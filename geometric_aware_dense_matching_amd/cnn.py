@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .layers import act_code, folded_bn, fused_eval
 
 
 def _conv3x3(cin, cout, stride=1, dilation=1):
@@ -38,6 +39,15 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if fused_eval(x, self):
+            # eval: conv -> [BN+ReLU] -> conv -> [BN + (BN'd) residual + ReLU], each bracket one HIP launch
+            s1, b1 = folded_bn(self.bn1)
+            out = ops.affine_act(self.conv1(x), s1, b1, ops.ACT_RELU)
+            s2, b2 = folded_bn(self.bn2)
+            if self.downsample is None:
+                return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=x)
+            sd, bd = folded_bn(self.downsample[1])
+            return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=self.downsample[0](x), res_scale=sd, res_shift=bd)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = x if self.downsample is None else self.downsample(x)
@@ -107,6 +117,13 @@ class PSPUpsample(nn.Module):
         self.conv = nn.Sequential(Upsample2x(), nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def forward(self, x):
+        if fused_eval(x, self):
+            code = act_code(self.conv[3])
+            if code is not None:
+                conv = self.conv[1]
+                y = F.conv2d(self.conv[0](x), conv.weight, None, conv.stride, conv.padding)     # bias folded into the shift
+                scale, shift = folded_bn(self.conv[2], conv.bias)
+                return ops.affine_act(y, scale, shift, code[0], code[1])
         return self.conv(x)
 
 

@@ -69,6 +69,42 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     atomicAdd(&p1[x1], ly * lx * g);
 }
 
+// y = act( x * sa[c] + ba[c]  (+ r * sr[c] + br[c]) ),  c = plane % C, planes x inner, fp32, may run in place.
+// Inference-mode BatchNorm (scale/shift folded on the host) + activation (+ residual branch) in ONE pass:
+// replaces MIOpenBatchNormFwdInferSpatialEst + clamp / leaky_relu / prelu / add launches (2.0 ms of a 17.4 ms step).
+// act: 0 none, 1 relu, 2 leaky relu / prelu with one slope.
+template <int ACT, bool HAS_RES, bool RES_AFFINE>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sa, const float* __restrict__ ba,
+                                                         const float* __restrict__ r, const float* __restrict__ sr, const float* __restrict__ br,
+                                                         int C, long inner4, float slope, float* __restrict__ y)
+{
+    const long plane = blockIdx.y;
+    const int c = (int)(plane % C);
+    const float a = sa[c], b = ba[c];
+    float ra = 1.f, rb = 0.f;
+    if (HAS_RES && RES_AFFINE) {
+        ra = sr[c];
+        rb = br[c];
+    }
+    const float4* xp = reinterpret_cast<const float4*>(x) + plane * inner4;
+    const float4* rp = HAS_RES ? reinterpret_cast<const float4*>(r) + plane * inner4 : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y) + plane * inner4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < inner4; i += (long)gridDim.x * 256) {
+        float4 v = xp[i];
+        float o[4] = {v.x * a + b, v.y * a + b, v.z * a + b, v.w * a + b};
+        if (HAS_RES) {
+            const float4 q = rp[i];
+            o[0] += q.x * ra + rb; o[1] += q.y * ra + rb; o[2] += q.z * ra + rb; o[3] += q.w * ra + rb;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ACT == 1) o[j] = fmaxf(o[j], 0.f);
+            if (ACT == 2) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+        }
+        yp[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -101,4 +137,25 @@ extern "C" int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes,
                            grad_out + p0 * OH * OW, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), grad_in + p0 * H * W);
     }
     return gdm_launch_status("upsample_bilinear_bwd_kernel");
+}
+
+extern "C" int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, const float* res, const float* res_scale,
+                                  const float* res_shift, long planes, int C, long inner, int act, float slope, float* y, void* stream)
+{
+    GDM_CHECK_ARG(x && scale && shift && y, "gdm_affine_act_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && planes <= 65535 && C >= 1 && inner >= 4 && inner % 4 == 0, "gdm_affine_act_hip: planes=%ld C=%d inner=%ld (inner %% 4 == 0, planes <= 65535)", planes, C, inner);
+    GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_affine_act_hip: act=%d", act);
+    GDM_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "gdm_affine_act_hip: pointers must be 16-byte aligned");
+    const long inner4 = inner / 4;
+    int gx = gdm_cdiv(inner4, 256);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, (unsigned)planes);
+    hipStream_t s = (hipStream_t)stream;
+#define AA(A, H, R) hipLaunchKernelGGL((affine_act_kernel<A, H, R>), grid, dim3(256), 0, s, x, scale, shift, res, res_scale, res_shift, C, inner4, slope, y)
+    const bool has = res != nullptr, aff = res_scale != nullptr && res_shift != nullptr;
+    if (act == 0) { if (!has) AA(0, false, false); else if (aff) AA(0, true, true); else AA(0, true, false); }
+    else if (act == 1) { if (!has) AA(1, false, false); else if (aff) AA(1, true, true); else AA(1, true, false); }
+    else { if (!has) AA(2, false, false); else if (aff) AA(2, true, true); else AA(2, true, false); }
+#undef AA
+    return gdm_launch_status("affine_act_kernel");
 }

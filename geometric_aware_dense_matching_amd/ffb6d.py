@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .cnn import PSPNet
-from .layers import pt_conv2d, rl_conv1d, rl_conv2d
+from .layers import folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
 from .randla import DilatedResBlock
 
 
@@ -98,7 +98,12 @@ class FFB6DEmb(nn.Module):
         return ops.gather_nn(feature, interp_idx).unsqueeze(3)
 
     def forward(self, inputs, end_points=None):
-        rgb_emb = self.cnn_pre_stages(inputs["rgb"])
+        if fused_eval(inputs["rgb"], self):
+            pre = self.cnn_pre_stages                                         # conv1, bn1, relu, maxpool
+            s0, b0 = folded_bn(pre[1])
+            rgb_emb = pre[3](ops.affine_act(pre[0](inputs["rgb"]), s0, b0, ops.ACT_RELU))
+        else:
+            rgb_emb = self.cnn_pre_stages(inputs["rgb"])
         p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
 
         ds_emb = []

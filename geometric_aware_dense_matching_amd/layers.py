@@ -7,7 +7,65 @@ Two flavours exist in the reference and both are needed:
   * models/RandLA/pytorch_utils.py:34-99 submodules `conv`, `bn.bn`, `activation`;
     default activation LeakyReLU(0.2); BN eps 1e-6, momentum 0.99 (:103-105)
 """
+import torch
 import torch.nn as nn
+
+from . import ops
+
+
+def fused_eval(x, module):
+    """True when the inference-only fused BN+activation kernel may replace the module chain: eval mode, GPU
+    tensor, autograd off (the kernel has no backward; training and gradient checks use the torch modules)."""
+    return (not module.training) and x.is_cuda and not torch.is_grad_enabled()
+
+
+def folded_bn(bn, conv_bias=None):
+    """(scale, shift) of an eval-mode BatchNorm, with an optional preceding conv bias folded in; cached on the
+    module and recomputed when any of its tensors changed (version counters / storage)."""
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ())
+    key = tuple((t._version, t.data_ptr()) for t in ts)
+    cache = bn.__dict__.get("_gdm_fold")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+            if conv_bias is not None:
+                shift = shift + conv_bias * scale
+        cache = (key, scale.contiguous(), shift.contiguous())
+        bn.__dict__["_gdm_fold"] = cache
+    return cache[1], cache[2]
+
+
+def act_code(act):
+    """(ops.ACT_*, slope) of an activation module; None when it is not one the fused kernel knows."""
+    if act is None:
+        return ops.ACT_NONE, 0.0
+    if isinstance(act, nn.ReLU):
+        return ops.ACT_RELU, 0.0
+    if isinstance(act, nn.LeakyReLU):
+        return ops.ACT_LEAKY, float(act.negative_slope)
+    if isinstance(act, nn.PReLU) and act.weight.numel() == 1:
+        key = (act.weight._version, act.weight.data_ptr())
+        cache = act.__dict__.get("_gdm_slope")
+        if cache is None or cache[0] != key:
+            cache = (key, float(act.weight.detach().item()))          # one host sync per weight change
+            act.__dict__["_gdm_slope"] = cache
+        return ops.ACT_LEAKY, cache[1]
+    return None
+
+
+class _FusedConvMixin:
+    _bn_name = None
+
+    def forward(self, x):
+        bnw = getattr(self, self._bn_name, None)
+        if bnw is not None and fused_eval(x, self):
+            code = act_code(getattr(self, "activation", None))
+            if code is not None and self.conv.bias is None:
+                y = self.conv(x)
+                scale, shift = folded_bn(bnw.bn)
+                return ops.affine_act(y, scale, shift, code[0], code[1])
+        return nn.Sequential.forward(self, x)
 
 
 class _BN(nn.Sequential):
@@ -18,8 +76,9 @@ class _BN(nn.Sequential):
         nn.init.constant_(self[0].bias, 0.0)
 
 
-class _PtConv(nn.Sequential):
+class _PtConv(_FusedConvMixin, nn.Sequential):
     """models/pytorch_utils.py:_ConvBase (non-preact form, the only one the hot path uses)."""
+    _bn_name = "normlayer"
 
     def __init__(self, conv_cls, bn_cls, cin, cout, kernel_size, bn, activation, bias):
         super().__init__()
@@ -63,8 +122,9 @@ class PtSeq(nn.Sequential):
         return self
 
 
-class _RlConv(nn.Sequential):
+class _RlConv(_FusedConvMixin, nn.Sequential):
     """models/RandLA/pytorch_utils.py:_ConvBase (non-preact, no instance norm)."""
+    _bn_name = "bn"
 
     def __init__(self, conv_cls, bn_cls, cin, cout, kernel_size, bn, activation, bias=True):
         super().__init__()

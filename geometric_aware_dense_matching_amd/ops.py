@@ -326,6 +326,37 @@ def circle_rows(sim, match, item, xyz, vis, radius, gamma=16.0, m=0.2):
     return _CircleRows.apply(sim, match, item, xyz, vis8, float(radius), float(gamma), float(m))
 
 
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def affine_act(x, scale, shift, act=ACT_NONE, slope=0.0, res=None, res_scale=None, res_shift=None, inplace=True):
+    """Inference only (no autograd): y = act(x*scale[c] + shift[c] (+ res*res_scale[c] + res_shift[c])) for
+    x f32[B,C,...] contiguous.  Folded eval BatchNorm + activation (+ residual) in one launch."""
+    x = _dev(x, torch.float32, "x")
+    B, C = x.shape[0], x.shape[1]
+    inner = x.numel() // (B * C)
+    if inner % 4 != 0 or B * C > 65535 or x.data_ptr() % 16 != 0:
+        y = x * scale.view(1, C, *([1] * (x.dim() - 2))) + shift.view(1, C, *([1] * (x.dim() - 2)))
+        if res is not None:
+            y = y + (res * res_scale.view_as(scale.view(1, C, *([1] * (x.dim() - 2)))) + res_shift.view(1, C, *([1] * (x.dim() - 2)))
+                     if res_scale is not None else res)
+        if act == ACT_RELU:
+            y = torch.relu(y)
+        elif act == ACT_LEAKY:
+            y = torch.where(y > 0, y, y * slope)
+        return y
+    if res is not None:
+        res = _dev(res, torch.float32, "res")
+        assert res.shape == x.shape
+    y = x if inplace else torch.empty_like(x)
+    check(_lib.lib().gdm_affine_act_hip(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                        res.data_ptr() if res is not None else None,
+                                        res_scale.data_ptr() if res_scale is not None else None,
+                                        res_shift.data_ptr() if res_shift is not None else None,
+                                        B * C, C, inner, act, float(slope), y.data_ptr(), _stream()), "gdm_affine_act_hip")
+    return y
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import rl_conv2d
+from .layers import folded_bn, fused_eval, rl_conv2d
 
 
 class AttPooling(nn.Module):
@@ -61,6 +61,11 @@ class DilatedResBlock(nn.Module):
     def forward(self, feature, xyz, neigh_idx):
         f_pc = self.mlp1(feature)
         f_pc = self.lfa(xyz, f_pc, neigh_idx)
+        if fused_eval(feature, self):
+            sa, ba = folded_bn(self.mlp2.bn.bn)
+            sr, br = folded_bn(self.shortcut.bn.bn)
+            return ops.affine_act(self.mlp2.conv(f_pc), sa, ba, ops.ACT_LEAKY, 0.2, res=self.shortcut.conv(feature),
+                                  res_scale=sr, res_shift=br)
         f_pc = self.mlp2(f_pc)
         shortcut = self.shortcut(feature)
         return F.leaky_relu(f_pc + shortcut, negative_slope=0.2)

@@ -204,6 +204,15 @@ int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* matc
 int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stride, int ch_stride, const float* model_xyz,
                          const int32_t* best_idx, const uint8_t* mask, int B, int N, int M, double* out, void* stream);
 
+/* Inference-mode BatchNorm + activation (+ residual branch with its own folded BatchNorm) in one pass:
+ * y = act(x*scale[c] + shift[c] (+ res*res_scale[c] + res_shift[c])), c = plane % C; x,res,y f32[planes, inner],
+ * inner % 4 == 0; res / res_scale / res_shift may be NULL (res_scale NULL = plain residual add).
+ * act: 0 none, 1 ReLU, 2 leaky ReLU / single-slope PReLU (slope).  May run in place (y == x).
+ * Replaces the BN / ReLU / LeakyReLU / PReLU / add launches of pytorch_utils._ConvBase, extractors.BasicBlock
+ * (extractors.py:36-58), PSPUpsample (pspnet.py:34-45) and Dilated_res_block (RandLANet.py:683-688) in eval mode. */
+int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, const float* res, const float* res_scale,
+                       const float* res_shift, long planes, int C, long inner, int act, float slope, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

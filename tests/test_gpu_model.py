@@ -318,3 +318,18 @@ def test_gpu_pose_solve_vs_reference_golden():
     assert np.abs(add - g["add"][:2]).max() < 1e-6 and np.abs(adi - g["adi"][:2]).max() < 1e-6
     det = torch.linalg.det(RT[:2, :, :3].double())
     assert torch.allclose(det, torch.ones_like(det), atol=1e-6)
+
+
+def test_fused_eval_path_equals_module_path(golden_model):
+    """Eval under no_grad uses the fused BN+activation(+residual) kernel; with autograd enabled the torch modules run.
+    Both must give the same forward (1e-5 relative: BN folded into scale/shift changes rounding)."""
+    from geometric_aware_dense_matching_amd import pyramid
+    model, _ = golden_model
+    batch = synthetic.make_batch(seed=31, batch=2, n_points=1024)
+    d = _dev_inputs(batch)
+    d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"]))
+    with torch.no_grad():
+        a = model(dict(d))
+    b = model(dict(d))                                   # grad enabled -> module path
+    for k in ("rgbd", "seg"):
+        assert torch.allclose(a[k], b[k].detach(), rtol=1e-4, atol=2e-4), k
