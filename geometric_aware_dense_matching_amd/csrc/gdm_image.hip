@@ -16,10 +16,14 @@ namespace {
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, int H, int W, int OH, int OW,
                                                                 float rh, float rw, float* __restrict__ out)
 {
-    const long plane = blockIdx.z;
-    const int oy = blockIdx.y;
-    const int ox0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (ox0 >= OW) return;
+    // one thread = 4 consecutive output pixels of one row; rows of a plane are flattened so that small maps
+    // (32x32 -> 64x64 has only 16 quads per row) still fill the wave
+    const long plane = blockIdx.y;
+    const int qpr = (OW + 3) >> 2;                       // quads per output row
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * OH) return;
+    const int oy = q / qpr;
+    const int ox0 = (q - oy * qpr) * 4;
     const float sy = rh * (float)oy;
     const int y0 = (int)sy;
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
@@ -112,13 +116,14 @@ inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (flo
 extern "C" int gdm_upsample_bilinear_hip(const float* in, long planes, int H, int W, int OH, int OW, float* out, void* stream)
 {
     GDM_CHECK_ARG(in && out, "gdm_upsample_bilinear_hip: NULL pointer");
-    GDM_CHECK_ARG(planes >= 1 && planes <= 65535L * 32768 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && OH <= 65535,
+    GDM_CHECK_ARG(planes >= 1 && planes <= 65535L * 32768 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1,
                   "gdm_upsample_bilinear_hip: bad shape planes=%ld %dx%d -> %dx%d", planes, H, W, OH, OW);
-    // planes ride blockIdx.z (<= 65535): fold the excess into repeated launches
+    // planes ride blockIdx.y (<= 65535): fold the excess into repeated launches
     const long zmax = 65535;
+    const int quads = ((OW + 3) / 4) * OH;
     for (long p0 = 0; p0 < planes; p0 += zmax) {
         const long np = planes - p0 < zmax ? planes - p0 : zmax;
-        dim3 grid(gdm_cdiv(gdm_cdiv(OW, 4), 256), OH, (unsigned)np);
+        dim3 grid(gdm_cdiv(quads, 256), (unsigned)np);
         hipLaunchKernelGGL(upsample_bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                            in + p0 * H * W, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), out + p0 * OH * OW);
     }
