@@ -109,6 +109,86 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
+// conv3x3(pad 1) o bilinear-upsample(align_corners) computed from LOW-resolution channel mixes.
+// Both operators are linear, and the 3x3 convolution's channel mixing commutes with the (per-channel)
+// interpolation, so
+//     conv3x3(up(x))[co](y,x) = sum_{tap=(dy,dx)} [ (y+dy,x+dx) inside ] * up( W_tap x )[co](y+dy, x+dx)
+// i.e. ONE 1x1 convolution Cin -> 9*Cout at the low resolution (a GEMM with 4x fewer FLOPs than the 3x3
+// convolution at 2x resolution) followed by this gather: per output pixel 9 bilinear taps of
+// z[b, tap*Cout + co] with zero fill outside the upsampled map, then the folded BatchNorm scale/shift and
+// the activation (PSPUpsample = Upsample + Conv3x3 + BN + PReLU, /root/reference/models/cnn/pspnet.py:34-45).
+// Exact in real arithmetic; fp32 rounding differs from conv-after-upsample only in summation order.
+// Removes the 2x-resolution input tensor entirely (never written, never read).
+template <int ACT>
+__global__ __launch_bounds__(256) void upconv3x3_gather_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int Cout, int H, int W, int OH, int OW,
+                                                               float rh, float rw, float slope, float* __restrict__ out)
+{
+    const int bc = blockIdx.y;                       // b * Cout + co
+    const int b = bc / Cout, co = bc - b * Cout;
+    const int qpr = (OW + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * OH) return;
+    const int oy = q / qpr;
+    const int ox0 = (q - oy * qpr) * 4;
+    // column parameters of the 6 source columns ox0-1 .. ox0+4
+    int cx0[6], cx1[6];
+    float clx[6];
+    bool cok[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ox = ox0 - 1 + j;
+        cok[j] = ox >= 0 && ox < OW;
+        const float sx = rw * (float)max(ox, 0);
+        const int x0 = min((int)sx, W - 1);
+        cx0[j] = x0;
+        cx1[j] = x0 + (x0 < W - 1 ? 1 : 0);
+        clx[j] = sx - (float)x0;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long plane_sz = (long)H * W;
+    const float* zb = z + ((long)b * 9 * Cout + co) * plane_sz;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = oy + dy;
+        if (yy < 0 || yy >= OH) continue;            // zero padding of the upsampled map
+        const float sy = rh * (float)yy;
+        const int y0 = min((int)sy, H - 1);
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, hy = 1.f - ly;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int tap = (dy + 1) * 3 + (dx + 1);
+            const float* zp = zb + (long)tap * Cout * plane_sz;
+            const float* r0 = zp + (long)y0 * W;
+            const float* r1 = zp + (long)y1 * W;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = j + dx + 1;            // index into the 6-column table
+                if (cok[c]) {
+                    const float lx = clx[c], hx = 1.f - lx;
+                    acc[j] += hy * (hx * r0[cx0[c]] + lx * r0[cx1[c]]) + ly * (hx * r1[cx0[c]] + lx * r1[cx1[c]]);
+                }
+            }
+        }
+    }
+    const float a = scale[co], sh = shift[co];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float o = acc[j] * a + sh;
+        if (ACT == 1) o = fmaxf(o, 0.f);
+        if (ACT == 2) o = o > 0.f ? o : o * slope;
+        v[j] = o;
+    }
+    float* op = out + ((long)bc * OH + oy) * OW + ox0;
+    if (ox0 + 3 < OW && (((uintptr_t)op) & 15) == 0) {
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int j = 0; j < 4 && ox0 + j < OW; ++j) op[j] = v[j];
+    }
+}
+
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -163,4 +243,21 @@ extern "C" int gdm_affine_act_hip(const float* x, const float* scale, const floa
     else { if (!has) AA(2, false, false); else if (aff) AA(2, true, true); else AA(2, true, false); }
 #undef AA
     return gdm_launch_status("affine_act_kernel");
+}
+
+extern "C" int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
+                                        int OH, int OW, int act, float slope, float* out, void* stream)
+{
+    GDM_CHECK_ARG(z && scale && shift && out, "gdm_upconv3x3_gather_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cout >= 1 && (long)B * Cout <= 65535 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1,
+                  "gdm_upconv3x3_gather_hip: bad shape B=%d Cout=%d %dx%d -> %dx%d", B, Cout, H, W, OH, OW);
+    GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_upconv3x3_gather_hip: act=%d", act);
+    const int quads = ((OW + 3) / 4) * OH;
+    dim3 grid(gdm_cdiv(quads, 256), B * Cout);
+    hipStream_t s = (hipStream_t)stream;
+    const float rh = scale_ac(H, OH), rw = scale_ac(W, OW);
+    if (act == 0) hipLaunchKernelGGL(upconv3x3_gather_kernel<0>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
+    else if (act == 1) hipLaunchKernelGGL(upconv3x3_gather_kernel<1>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
+    else hipLaunchKernelGGL(upconv3x3_gather_kernel<2>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
+    return gdm_launch_status("upconv3x3_gather_kernel");
 }

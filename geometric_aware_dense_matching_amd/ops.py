@@ -357,6 +357,19 @@ def affine_act(x, scale, shift, act=ACT_NONE, slope=0.0, res=None, res_scale=Non
     return y
 
 
+def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
+    """z f32[B, 9*cout, H, W] (low-resolution tap-major channel mixes) -> f32[B, cout, OH, OW]: the 9-tap bilinear
+    gather that completes conv3x3(upsample(x)) + folded BN + activation.  Inference only."""
+    z = _dev(z, torch.float32, "z")
+    B, c9, H, W = z.shape
+    assert c9 == 9 * cout
+    OH, OW = int(out_size[0]), int(out_size[1])
+    out = torch.empty((B, cout, OH, OW), dtype=torch.float32, device=z.device)
+    check(_lib.lib().gdm_upconv3x3_gather_hip(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, cout, H, W, OH, OW, act,
+                                              float(slope), out.data_ptr(), _stream()), "gdm_upconv3x3_gather_hip")
+    return out
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

@@ -213,6 +213,13 @@ int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stri
 int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, const float* res, const float* res_scale,
                        const float* res_shift, long planes, int C, long inner, int act, float slope, float* y, void* stream);
 
+/* conv3x3(pad 1) after bilinear upsample (align_corners), from low-resolution channel mixes (pspnet.py:34-45):
+ * z f32[B, 9*Cout, H, W] = conv1x1(x, W rearranged tap-major) at LOW resolution; this gathers, per output pixel,
+ * the 9 bilinear taps (zero outside the OHxOW map), applies scale/shift (folded BN incl. the conv bias) and the
+ * activation (0 none, 1 ReLU, 2 leaky/PReLU slope) -> out f32[B, Cout, OH, OW].                              */
+int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
+                             int OH, int OW, int act, float slope, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

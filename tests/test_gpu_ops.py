@@ -299,3 +299,20 @@ def test_edge_feature_and_backward(ops):
     b = x.clone().cuda().requires_grad_(True)
     (ops.edge_feature(b, idx.cuda()) * w.cuda()).sum().backward()
     assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 8, 32, 32), (1, 5, 3, 7, 9), (2, 64, 64, 16, 16)])
+def test_upconv3x3_gather_equals_conv_after_upsample(ops, B, Cin, Cout, H, W):
+    """conv3x3(pad 1)(bilinear_up_x2(x)) + per-channel affine + leaky == low-res 1x1 conv + 9-tap gather."""
+    rs = np.random.RandomState(B * 100 + Cin)
+    x = torch.from_numpy(rs.randn(B, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(np.float32))
+    scale = torch.from_numpy((1 + 0.1 * rs.randn(Cout)).astype(np.float32))
+    shift = torch.from_numpy((0.1 * rs.randn(Cout)).astype(np.float32))
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    want = torch.nn.functional.conv2d(up, w, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.25)
+    wt = w.permute(2, 3, 0, 1).reshape(9 * Cout, Cin, 1, 1).contiguous()
+    z = torch.nn.functional.conv2d(x.cuda(), wt.cuda())
+    got = ops.upconv3x3_gather(z, scale.cuda(), shift.cuda(), Cout, (2 * H, 2 * W), ops.ACT_LEAKY, 0.25).cpu()
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
