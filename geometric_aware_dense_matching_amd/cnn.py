@@ -117,13 +117,13 @@ class PSPUpsample(nn.Module):
         self.conv = nn.Sequential(Upsample2x(), nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def _tap_major_weight(self):
-        """[Cout,Cin,3,3] -> [9*Cout,Cin,1,1], row = tap*Cout + co; cached until the weight changes."""
+        """[Cout,Cin,3,3] -> [9*Cout,Cin], row = tap*Cout + co; cached until the weight changes."""
         w = self.conv[1].weight
         key = (w._version, w.data_ptr())
         cache = self.__dict__.get("_gdm_wt")
         if cache is None or cache[0] != key:
             with torch.no_grad():
-                wt = w.permute(2, 3, 0, 1).reshape(9 * w.shape[0], w.shape[1], 1, 1).contiguous()
+                wt = w.permute(2, 3, 0, 1).reshape(9 * w.shape[0], w.shape[1]).contiguous()
             cache = (key, wt)
             self.__dict__["_gdm_wt"] = cache
         return cache[1]
@@ -135,7 +135,8 @@ class PSPUpsample(nn.Module):
             if code is not None and x.shape[0] * conv.out_channels <= 65535:
                 # conv3x3(up(x)) = 9-tap bilinear gather of a LOW-resolution 1x1 convolution (4x fewer FLOPs, no
                 # 2x-resolution intermediate), BN (with the conv bias) + PReLU folded into the gather's epilogue
-                z = F.conv2d(x, self._tap_major_weight())
+                Bx, Cin, Hx, Wx = x.shape
+                z = torch.matmul(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
                 scale, shift = folded_bn(self.conv[2], conv.bias)
                 return ops.upconv3x3_gather(z, scale, shift, conv.out_channels, (x.shape[2] * 2, x.shape[3] * 2), code[0], code[1])
         return self.conv(x)
