@@ -97,8 +97,37 @@ class PSPModule(nn.Module):
         self.bottleneck = nn.Conv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
         self.relu = nn.ReLU()
 
+    def _split_weights(self):
+        """Bottleneck weight split over the concat [prior_1..prior_4, feats] with each prior's own 1x1 conv folded in:
+        M_k = W[:, kF:(k+1)F] @ V_k (so W_k . up(V_k pool_k f) = up(M_k pool_k f)), W_f = W[:, 4F:].  Cached."""
+        w = self.bottleneck.weight
+        vs = [st[1].weight for st in self.stages]
+        key = tuple((t._version, t.data_ptr()) for t in [w] + vs)
+        cache = self.__dict__.get("_gdm_split")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                F_ = vs[0].shape[0]
+                w2 = w.view(w.shape[0], -1)
+                ms = [(w2[:, k * F_:(k + 1) * F_] @ v.view(F_, F_)).contiguous() for k, v in enumerate(vs)]
+                wf = w2[:, len(vs) * F_:].contiguous()
+            cache = (key, ms, wf)
+            self.__dict__["_gdm_split"] = cache
+        return cache[1], cache[2]
+
     def forward(self, feats):
         h, w = feats.size(2), feats.size(3)
+        if fused_eval(feats, self) and len(self.stages) == 4 and feats.shape[0] * self.bottleneck.out_channels <= 65535:
+            # relu(W cat(up(p_k)..., f) + b) = relu(W_f f + b + sum_k up(M_k pool_k f)): K = 512 instead of 2560, no concat,
+            # no full-resolution priors
+            ms, wf = self._split_weights()
+            B, Cin = feats.shape[0], feats.shape[1]
+            g = torch.matmul(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
+            ys = []
+            for st, m in zip(self.stages, ms):
+                p = st[0](feats)                                            # adaptive average pool to s x s
+                s_ = p.shape[2]
+                ys.append(torch.matmul(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
+            return ops.psp_combine(g, ys, self.bottleneck.bias)
         priors = [ops.upsample_bilinear(stage(feats), (h, w)) for stage in self.stages] + [feats]
         return self.relu(self.bottleneck(torch.cat(priors, 1)))
 

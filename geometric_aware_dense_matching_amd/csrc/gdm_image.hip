@@ -276,6 +276,70 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
     }
 }
 
+// Pyramid-pooling bottleneck without the 2560-channel concat (pspnet.py:24-31):
+//   relu(W . cat(up(p1), up(p2), up(p3), up(p6), f) + b) = relu(W_f f + b + sum_s up(W_s p_s))
+// (1x1 convolution commutes with bilinear interpolation).  g = W_f f is a GEMM with K = 512 instead of 2560;
+// the four W_s p_s live at 1x1..6x6 and this kernel adds their interpolations, the bias and the ReLU.
+struct PspMaps {
+    const float* y[4];      // f32[B, C, s, s]
+    int s[4];
+};
+
+__global__ __launch_bounds__(256) void psp_combine_kernel(const float* __restrict__ g, PspMaps maps, const float* __restrict__ bias,
+                                                          int C, int H, int W, float* __restrict__ out)
+{
+    const long plane = blockIdx.y;                    // b * C + c
+    const int c = (int)(plane % C);
+    const int hw = H * W;
+    float sy[4], sx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sy[k] = H > 1 ? (float)(maps.s[k] - 1) / (float)(H - 1) : 0.f;
+        sx[k] = W > 1 ? (float)(maps.s[k] - 1) / (float)(W - 1) : 0.f;
+    }
+    const float bc = bias ? bias[c] : 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const int oy = i / W, ox = i - oy * W;
+        float v = g[plane * hw + i] + bc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int S = maps.s[k];
+            const float* m = maps.y[k] + plane * S * S;
+            const float fy = sy[k] * (float)oy, fx = sx[k] * (float)ox;
+            const int y0 = min((int)fy, S - 1), x0 = min((int)fx, S - 1);
+            const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            v += (1.f - ly) * ((1.f - lx) * m[y0 * S + x0] + lx * m[y0 * S + x1]) + ly * ((1.f - lx) * m[y1 * S + x0] + lx * m[y1 * S + x1]);
+        }
+        out[plane * hw + i] = fmaxf(v, 0.f);
+    }
+}
+
+// y[b,c,j] = act(scale[c] * (x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]) : the point->pixel fusion layers
+// conv1x1(cat(rgb, nearest_interp(p))) + BN + ReLU (ffb6d.py:216-222,252-258) with the point half of the
+// convolution done at the (few) points and gathered afterwards (a 1x1 convolution commutes with a gather).
+template <int ACT>
+__global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                                    const int32_t* __restrict__ idx, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int C, int n, int m, float slope,
+                                                                    float* __restrict__ y)
+{
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * 8;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    int src = idx[(long)b * m + j];
+    src = min(max(src, 0), n - 1);
+    const int cend = min(c0 + 8, C);
+    for (int c = c0; c < cend; ++c) {
+        const long row = (long)b * C + c;
+        float o = scale[c] * (x[row * m + j] + t[row * n + src]) + shift[c];
+        if (ACT == 1) o = fmaxf(o, 0.f);
+        if (ACT == 2) o = o > 0.f ? o : o * slope;
+        y[row * m + j] = o;
+    }
+}
+
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -353,4 +417,32 @@ extern "C" int gdm_upconv3x3_gather_hip(const float* z, const float* scale, cons
     const int quads = ((OW + 3) / 4) * OH;
     dim3 grid(gdm_cdiv(quads, 256), B * Cout);
     return gdm_launch_status("upconv3x3_gather_kernel");
+}
+
+extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
+                                   const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* stream)
+{
+    GDM_CHECK_ARG(g && y1 && y2 && y3 && y4 && out, "gdm_psp_combine_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && C >= 1 && (long)B * C <= 65535 && H >= 1 && W >= 1 && s1 >= 1 && s2 >= 1 && s3 >= 1 && s4 >= 1,
+                  "gdm_psp_combine_hip: bad shape");
+    PspMaps maps;
+    maps.y[0] = y1; maps.y[1] = y2; maps.y[2] = y3; maps.y[3] = y4;
+    maps.s[0] = s1; maps.s[1] = s2; maps.s[2] = s3; maps.s[3] = s4;
+    int gx = gdm_cdiv((long)H * W, 256);
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(psp_combine_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, g, maps, bias, C, H, W, out);
+    return gdm_launch_status("psp_combine_kernel");
+}
+
+extern "C" int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
+                                             int B, int C, int n, int m, int act, float slope, float* y, void* stream)
+{
+    GDM_CHECK_ARG(x && t && idx && scale && shift && y, "gdm_gather_add_affine_act_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && n >= 1 && m >= 1 && act >= 0 && act <= 2, "gdm_gather_add_affine_act_hip: bad shape");
+    dim3 grid(gdm_cdiv(m, 256), gdm_cdiv(C, 8), B);
+    hipStream_t s = (hipStream_t)stream;
+    if (act == 0) hipLaunchKernelGGL(gather_add_affine_act_kernel<0>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
+    else if (act == 1) hipLaunchKernelGGL(gather_add_affine_act_kernel<1>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
+    else hipLaunchKernelGGL(gather_add_affine_act_kernel<2>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
+    return gdm_launch_status("gather_add_affine_act_kernel");
 }

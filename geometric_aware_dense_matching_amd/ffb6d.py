@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .cnn import PSPNet
-from .layers import folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
+from .layers import act_code, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
 from .randla import DilatedResBlock
 
 
@@ -97,6 +97,36 @@ class FFB6DEmb(nn.Module):
     def nearest_interpolation(feature, interp_idx):
         return ops.gather_nn(feature, interp_idx).unsqueeze(3)
 
+    @staticmethod
+    def _split_fuse_weight(layer, c_first):
+        """1x1 fuse conv over cat(a, b): W = [W_a | W_b] split at channel c_first (contiguous copies, cached)."""
+        w = layer.conv.weight
+        key = (w._version, w.data_ptr(), c_first)
+        cache = layer.__dict__.get("_gdm_split")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w2 = w.view(w.shape[0], -1)
+                cache = (key, w2[:, :c_first].contiguous(), w2[:, c_first:].contiguous())
+            layer.__dict__["_gdm_split"] = cache
+        return cache[1], cache[2]
+
+    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx):
+        """fuse(cat(rgb_emb0, nearest_interp(pre(p_emb0)))) (ffb6d.py:216-222,252-258).  Eval: the point half of the
+        1x1 fuse convolution runs at the points (a 1x1 conv commutes with the gather), the pixel half is a GEMM with half
+        the K, and gather + add + BN + ReLU is one HIP launch; no concat, no full-resolution point features."""
+        bs, c, hr, wr = rgb_emb0.shape
+        if fused_eval(rgb_emb0, self):
+            code = act_code(getattr(fuse_layer, "activation", None))
+            if code is not None:
+                wa, wb = self._split_fuse_weight(fuse_layer, c)
+                t = torch.matmul(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
+                x = torch.matmul(wa, rgb_emb0.reshape(bs, c, hr * wr))                        # [B,Cout,HW]
+                scale, shift = folded_bn(fuse_layer.normlayer.bn)
+                y = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1])
+                return y.view(bs, -1, hr, wr)
+        p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)
+        return fuse_layer(torch.cat((rgb_emb0, p2r_emb), dim=1))
+
     def forward(self, inputs, end_points=None):
         if fused_eval(inputs["rgb"], self):
             pre = self.cnn_pre_stages                                         # conv1, bn1, relu, maxpool
@@ -116,9 +146,8 @@ class FFB6DEmb(nn.Module):
             if i_ds == 0:
                 ds_emb.append(f_encoder_i)
 
-            p2r_emb = self.ds_fuse_p2r_pre_layers[i_ds](p_emb0)
-            p2r_emb = self.nearest_interpolation(p2r_emb, inputs["p2r_ds_nei_idx%d" % i_ds]).view(bs, -1, hr, wr)
-            rgb_emb = self.ds_fuse_p2r_fuse_layers[i_ds](torch.cat((rgb_emb0, p2r_emb), dim=1))
+            rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,
+                                     inputs["p2r_ds_nei_idx%d" % i_ds])
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
             r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
@@ -133,9 +162,8 @@ class FFB6DEmb(nn.Module):
             f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])
             p_emb0 = self.rndla_up_stages[i_up](torch.cat([ds_emb[-i_up - 2], f_interp_i], dim=1))
 
-            p2r_emb = self.up_fuse_p2r_pre_layers[i_up](p_emb0)
-            p2r_emb = self.nearest_interpolation(p2r_emb, inputs["p2r_up_nei_idx%d" % i_up]).view(bs, -1, hr, wr)
-            rgb_emb = self.up_fuse_p2r_fuse_layers[i_up](torch.cat((rgb_emb0, p2r_emb), dim=1))
+            rgb_emb = self._p2r_fuse(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], rgb_emb0, p_emb0,
+                                     inputs["p2r_up_nei_idx%d" % i_up])
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_up_nei_idx%d" % i_up])
             r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)

@@ -370,6 +370,33 @@ def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
     return out
 
 
+def psp_combine(g, ys, bias):
+    """out = relu(g + bias + sum_k bilinear_up(ys[k])); g f32[B,C,H,W], ys four f32[B,C,s,s].  Inference only, in place on g."""
+    g = _dev(g, torch.float32, "g")
+    B, C, H, W = g.shape
+    ys = [_dev(y, torch.float32, "y") for y in ys]
+    assert len(ys) == 4
+    check(_lib.lib().gdm_psp_combine_hip(g.data_ptr(), ys[0].data_ptr(), ys[0].shape[2], ys[1].data_ptr(), ys[1].shape[2],
+                                         ys[2].data_ptr(), ys[2].shape[2], ys[3].data_ptr(), ys[3].shape[2],
+                                         bias.data_ptr() if bias is not None else None, B, C, H, W, g.data_ptr(), _stream()),
+          "gdm_psp_combine_hip")
+    return g
+
+
+def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
+    """y[b,c,j] = act(scale[c]*(x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]); x f32[B,C,m], t f32[B,C,n], idx int[B,m(,1)].
+    Inference only, in place on x."""
+    x = _dev(x, torch.float32, "x")
+    t = _dev(t, torch.float32, "t")
+    idx = _idx32(idx, "idx")
+    B, C, m = x.shape
+    n = t.shape[2]
+    check(_lib.lib().gdm_gather_add_affine_act_hip(x.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   B, C, n, m, act, float(slope), x.data_ptr(), _stream()),
+          "gdm_gather_add_affine_act_hip")
+    return x
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

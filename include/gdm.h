@@ -220,6 +220,15 @@ int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, c
 int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
                              int OH, int OW, int act, float slope, float* out, void* stream);
 
+/* Pyramid-pooling bottleneck tail (pspnet.py:24-31) after splitting the 1x1 convolution over the concat:
+ * out = relu(g + bias[c] + sum_k bilinear_align_corners(y_k)), g f32[B,C,H,W] = W_f . feats, y_k f32[B,C,s_k,s_k] = W_k . prior_k. */
+int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
+                        const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* stream);
+/* Point->pixel fusion tail (ffb6d.py:216-222,252-258): y[b,c,j] = act(scale[c]*(x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]),
+ * x f32[B,C,m] (pixel half of the 1x1 conv), t f32[B,C,n] (point half, computed at the points), idx i32[B,m]. May run in place. */
+int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
+                                  int B, int C, int n, int m, int act, float slope, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
