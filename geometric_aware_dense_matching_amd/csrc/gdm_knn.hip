@@ -20,6 +20,7 @@
 //     support index (the reference orders them by KD-tree traversal, which is not reproducible).
 #include "gdm_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -179,6 +180,96 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
     }
 }
 
+// ---- K > 1: one query per group of G lanes, the sorted top-K list DISTRIBUTED over the group's lanes ----
+// Lane g of a group holds the g-th best (d2, index) so far.  Each step the G lanes evaluate G consecutive
+// support points; candidates below the current K-th distance are inserted one at a time, lowest lane (= lowest
+// index) first: position = popcount(ballot(list <= cand)), the tail shifts up by one lane (__shfl_up) and the
+// K-th distance is re-broadcast.  An insertion costs ~15 wave instructions instead of the ~80 of a per-lane
+// register list, and the admission threshold is the query's GLOBAL K-th distance, so insertions happen
+// ~K(1+ln(S/K)) times per query instead of that many times per lane.
+template <int G>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_group_kernel(const KnnTable tab)
+{
+    __shared__ float4 tile[KNN_TILE];
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
+    const KnnJobDev& job = tab.jobs[j];
+    const int local = bid - job.block_begin;
+    const int b = local / job.blocks_per_b;
+    const int qb = local - b * job.blocks_per_b;
+    const int S = job.S, Q = job.Q, K = job.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = tid & (G - 1);                     // lane within the group
+    const int gbase = lane & ~(G - 1);               // first wave-lane of the group
+    const int q = qb * (KNN_BLOCK / G) + tid / G;
+    const bool valid = q < Q;
+    const int qc = valid ? q : Q - 1;
+    const float* sup = job.support + (long long)b * job.support_bstride;
+    const float* qry = job.query + (long long)b * job.query_bstride + (long long)qc * 3;
+    const float qx = qry[0], qy = qry[1], qz = qry[2];
+    const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+
+    float ld = INFINITY;                             // this lane's list element
+    int li = IDX_EMPTY;
+    float worst = INFINITY;                          // list[K-1], identical in all lanes of the group
+
+    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
+        __syncthreads();
+        const int npt = min(KNN_TILE, S - tile0);
+        for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
+            float4 v;
+            if (p < npt) {
+                const float* s3 = sup + (long long)(tile0 + p) * 3;
+                v = make_float4(s3[0], s3[1], s3[2], 0.f);
+            } else {
+                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            }
+            tile[p] = v;
+        }
+        __syncthreads();
+        const int steps = (npt + G - 1) / G;
+        for (int s = 0; s < steps; ++s) {
+            const int p = s * G + g;
+            const float4 v = tile[p];
+            const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
+            bool pass = d < worst;                   // strict: equal distance, higher index -> rejected
+            unsigned long long bal = __ballot(pass);
+            while (bal) {                            // wave-uniform loop
+                const unsigned long long m = (bal >> gbase) & gmask;
+                const bool act = m != 0ull;          // group-uniform
+                const int src = act ? __builtin_ctzll(m) : 0;
+                const float cd = __shfl(d, gbase + src, 64);
+                const int ci = tile0 + s * G + src;
+                const unsigned long long le = (__ballot(ld <= cd) >> gbase) & gmask & kmask;
+                const int pos = __builtin_popcountll(le);        // entries that stay in front (<=: earlier index wins ties)
+                const float ud = __shfl_up(ld, 1, G);
+                const int ui = __shfl_up(li, 1, G);
+                if (act) {
+                    if (g > pos) {
+                        ld = ud;
+                        li = ui;
+                    } else if (g == pos) {
+                        ld = cd;
+                        li = ci;
+                    }
+                }
+                worst = __shfl(ld, gbase + K - 1, 64);
+                pass = pass && !(act && g == src) && d < worst;
+                bal = __ballot(pass);
+            }
+        }
+    }
+    if (valid && g < K) {
+        int32_t* out_i = job.idx + ((long long)b * Q + q) * K;
+        out_i[g] = li == IDX_EMPTY ? 0 : li;
+        if (job.d2) job.d2[((long long)b * Q + q) * K + g] = isinf(ld) ? 3.402823466e+38f : ld;
+    }
+}
+
 int kmax_class(int K)
 {
     if (K <= 1) return 1;
@@ -193,6 +284,44 @@ int pick_logT(int S)
     int logT = 0;
     while (logT < 6 && (S >> (logT + 1)) >= 128) ++logT;
     return logT;
+}
+
+int group_class(int K) { return K <= 16 ? 16 : 32; }
+
+template <int G>
+int launch_group(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
+{
+    KnnTable tab;
+    tab.njobs = 0;
+    tab.B = B;
+    int nblocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (jobs[i].K < 2 || group_class(jobs[i].K) != G) continue;
+        KnnJobDev& d = tab.jobs[tab.njobs++];
+        d.support = jobs[i].support;
+        d.query = jobs[i].query;
+        d.idx = jobs[i].idx;
+        d.d2 = jobs[i].d2;
+        d.support_bstride = jobs[i].support_bstride;
+        d.query_bstride = jobs[i].query_bstride;
+        d.S = jobs[i].S;
+        d.Q = jobs[i].Q;
+        d.K = jobs[i].K;
+        d.logT = 0;
+        d.blocks_per_b = gdm_cdiv(d.Q, KNN_BLOCK / G);
+        d.block_begin = nblocks;
+        nblocks += d.blocks_per_b * B;
+    }
+    if (tab.njobs == 0) return 0;
+    hipLaunchKernelGGL(knn_group_kernel<G>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+    return gdm_launch_status("knn_group_kernel");
+}
+
+// 1 = per-lane register lists (first version, kept for A/B), 2 = lane-distributed list (default); GDM_KNN_KERNEL overrides
+int knn_kernel_version()
+{
+    const char* e = getenv("GDM_KNN_KERNEL");
+    return (e && e[0] == '1') ? 1 : 2;
 }
 
 template <int KMAX>
@@ -242,6 +371,10 @@ extern "C" int gdm_knn_jobs_hip(const gdm_knn_job* jobs, int njobs, int B, void*
     }
     int rc;
     if ((rc = launch_class<1>(jobs, njobs, B, stream))) return rc;
+    if (knn_kernel_version() == 2) {
+        if ((rc = launch_group<16>(jobs, njobs, B, stream))) return rc;
+        return launch_group<32>(jobs, njobs, B, stream);
+    }
     if ((rc = launch_class<8>(jobs, njobs, B, stream))) return rc;
     if ((rc = launch_class<16>(jobs, njobs, B, stream))) return rc;
     if ((rc = launch_class<32>(jobs, njobs, B, stream))) return rc;
