@@ -286,7 +286,17 @@ int pick_logT(int S)
     return logT;
 }
 
+int knn_kernel_version();
 int group_class(int K) { return K <= 16 ? 16 : 32; }
+
+// Which kernel serves a K > 1 job: the lane-distributed list needs one group per query, so with few queries
+// against a large support set (e.g. 16384 pixels -> 128 points) it leaves the chip idle; those jobs keep the
+// per-lane-list kernel, which splits ONE query's support over up to 64 lanes.
+bool use_group_kernel(const gdm_knn_job& j, int B)
+{
+    if (knn_kernel_version() != 2 || j.K < 2) return false;
+    return (long)B * j.Q >= 4096 || j.S <= 512;
+}
 
 template <int G>
 int launch_group(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
@@ -296,7 +306,7 @@ int launch_group(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     tab.B = B;
     int nblocks = 0;
     for (int i = 0; i < njobs; ++i) {
-        if (jobs[i].K < 2 || group_class(jobs[i].K) != G) continue;
+        if (!use_group_kernel(jobs[i], B) || group_class(jobs[i].K) != G) continue;
         KnnJobDev& d = tab.jobs[tab.njobs++];
         d.support = jobs[i].support;
         d.query = jobs[i].query;
@@ -332,7 +342,7 @@ int launch_class(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     tab.B = B;
     int nblocks = 0;
     for (int i = 0; i < njobs; ++i) {
-        if (kmax_class(jobs[i].K) != KMAX) continue;
+        if (kmax_class(jobs[i].K) != KMAX || use_group_kernel(jobs[i], B)) continue;
         KnnJobDev& d = tab.jobs[tab.njobs++];
         d.support = jobs[i].support;
         d.query = jobs[i].query;
@@ -371,10 +381,8 @@ extern "C" int gdm_knn_jobs_hip(const gdm_knn_job* jobs, int njobs, int B, void*
     }
     int rc;
     if ((rc = launch_class<1>(jobs, njobs, B, stream))) return rc;
-    if (knn_kernel_version() == 2) {
-        if ((rc = launch_group<16>(jobs, njobs, B, stream))) return rc;
-        return launch_group<32>(jobs, njobs, B, stream);
-    }
+    if ((rc = launch_group<16>(jobs, njobs, B, stream))) return rc;
+    if ((rc = launch_group<32>(jobs, njobs, B, stream))) return rc;
     if ((rc = launch_class<8>(jobs, njobs, B, stream))) return rc;
     if ((rc = launch_class<16>(jobs, njobs, B, stream))) return rc;
     if ((rc = launch_class<32>(jobs, njobs, B, stream))) return rc;
