@@ -327,11 +327,14 @@ int launch_group(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     return gdm_launch_status("knn_group_kernel");
 }
 
-// 1 = per-lane register lists (first version, kept for A/B), 2 = lane-distributed list (default); GDM_KNN_KERNEL overrides
+// 1 = per-lane register lists, every K > 1 job of a batch in ONE launch (default);
+// 2 = lane-distributed list for the query-rich jobs (GDM_KNN_KERNEL=2).  Measured on MI355X (B=16 pyramid):
+// v2 wins per job in isolation (2048x2048: 106 vs 182 us, 16384->512: 172 vs 343 us) but splitting the K=16 jobs over
+// two serial launches loses the cross-job overlap: 1.18 ms vs 0.73 ms per pyramid.  Next step: one launch, both bodies.
 int knn_kernel_version()
 {
     const char* e = getenv("GDM_KNN_KERNEL");
-    return (e && e[0] == '1') ? 1 : 2;
+    return (e && e[0] == '2') ? 2 : 1;
 }
 
 template <int KMAX>
