@@ -59,6 +59,84 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float p
     return r;
 }
 
+template <int G>
+__device__ __forceinline__ void knn_group_body(const KnnJobDev& job, int local, float4* tile)
+{
+    const int b = local / job.blocks_per_b;
+    const int qb = local - b * job.blocks_per_b;
+    const int S = job.S, Q = job.Q, K = job.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = tid & (G - 1);                     // lane within the group
+    const int gbase = lane & ~(G - 1);               // first wave-lane of the group
+    const int q = qb * (KNN_BLOCK / G) + tid / G;
+    const bool valid = q < Q;
+    const int qc = valid ? q : Q - 1;
+    const float* sup = job.support + (long long)b * job.support_bstride;
+    const float* qry = job.query + (long long)b * job.query_bstride + (long long)qc * 3;
+    const float qx = qry[0], qy = qry[1], qz = qry[2];
+    const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+
+    float ld = INFINITY;                             // this lane's list element
+    int li = IDX_EMPTY;
+    float worst = INFINITY;                          // list[K-1], identical in all lanes of the group
+
+    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
+        __syncthreads();
+        const int npt = min(KNN_TILE, S - tile0);
+        for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
+            float4 v;
+            if (p < npt) {
+                const float* s3 = sup + (long long)(tile0 + p) * 3;
+                v = make_float4(s3[0], s3[1], s3[2], 0.f);
+            } else {
+                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            }
+            tile[p] = v;
+        }
+        __syncthreads();
+        const int steps = (npt + G - 1) / G;
+        for (int s = 0; s < steps; ++s) {
+            const int p = s * G + g;
+            const float4 v = tile[p];
+            const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
+            bool pass = d < worst;                   // strict: equal distance, higher index -> rejected
+            unsigned long long bal = __ballot(pass);
+            while (bal) {                            // wave-uniform loop
+                const unsigned long long m = (bal >> gbase) & gmask;
+                const bool act = m != 0ull;          // group-uniform
+                const int src = act ? __builtin_ctzll(m) : 0;
+                const float cd = __shfl(d, gbase + src, 64);
+                const int ci = tile0 + s * G + src;
+                const unsigned long long le = (__ballot(ld <= cd) >> gbase) & gmask & kmask;
+                const int pos = __builtin_popcountll(le);        // entries that stay in front (<=: earlier index wins ties)
+                const float ud = __shfl_up(ld, 1, G);
+                const int ui = __shfl_up(li, 1, G);
+                if (act) {
+                    if (g > pos) {
+                        ld = ud;
+                        li = ui;
+                    } else if (g == pos) {
+                        ld = cd;
+                        li = ci;
+                    }
+                }
+                worst = __shfl(ld, gbase + K - 1, 64);
+                pass = pass && !(act && g == src) && d < worst;
+                bal = __ballot(pass);
+            }
+        }
+    }
+    if (valid && g < K) {
+        int32_t* out_i = job.idx + ((long long)b * Q + q) * K;
+        out_i[g] = li == IDX_EMPTY ? 0 : li;
+        if (job.d2) job.d2[((long long)b * Q + q) * K + g] = isinf(ld) ? 3.402823466e+38f : ld;
+    }
+}
+
+
 template <int KMAX>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
 {
@@ -70,6 +148,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
     while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
     const KnnJobDev& job = tab.jobs[j];
     const int local = bid - job.block_begin;
+    if (job.logT < 0) {                               // query-rich job: lane-distributed list, same launch
+        if (KMAX == 16) knn_group_body<16>(job, local, tile);
+        else if (KMAX == 32) knn_group_body<32>(job, local, tile);
+        return;
+    }
     const int b = local / job.blocks_per_b;
     const int qb = local - b * job.blocks_per_b;
     const int logT = job.logT;
@@ -194,80 +277,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_group_kernel(const KnnTable tab
     const int bid = blockIdx.x;
     int j = 0;
     while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
-    const KnnJobDev& job = tab.jobs[j];
-    const int local = bid - job.block_begin;
-    const int b = local / job.blocks_per_b;
-    const int qb = local - b * job.blocks_per_b;
-    const int S = job.S, Q = job.Q, K = job.K;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int g = tid & (G - 1);                     // lane within the group
-    const int gbase = lane & ~(G - 1);               // first wave-lane of the group
-    const int q = qb * (KNN_BLOCK / G) + tid / G;
-    const bool valid = q < Q;
-    const int qc = valid ? q : Q - 1;
-    const float* sup = job.support + (long long)b * job.support_bstride;
-    const float* qry = job.query + (long long)b * job.query_bstride + (long long)qc * 3;
-    const float qx = qry[0], qy = qry[1], qz = qry[2];
-    const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
-
-    float ld = INFINITY;                             // this lane's list element
-    int li = IDX_EMPTY;
-    float worst = INFINITY;                          // list[K-1], identical in all lanes of the group
-
-    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
-        __syncthreads();
-        const int npt = min(KNN_TILE, S - tile0);
-        for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
-            float4 v;
-            if (p < npt) {
-                const float* s3 = sup + (long long)(tile0 + p) * 3;
-                v = make_float4(s3[0], s3[1], s3[2], 0.f);
-            } else {
-                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-            }
-            tile[p] = v;
-        }
-        __syncthreads();
-        const int steps = (npt + G - 1) / G;
-        for (int s = 0; s < steps; ++s) {
-            const int p = s * G + g;
-            const float4 v = tile[p];
-            const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
-            bool pass = d < worst;                   // strict: equal distance, higher index -> rejected
-            unsigned long long bal = __ballot(pass);
-            while (bal) {                            // wave-uniform loop
-                const unsigned long long m = (bal >> gbase) & gmask;
-                const bool act = m != 0ull;          // group-uniform
-                const int src = act ? __builtin_ctzll(m) : 0;
-                const float cd = __shfl(d, gbase + src, 64);
-                const int ci = tile0 + s * G + src;
-                const unsigned long long le = (__ballot(ld <= cd) >> gbase) & gmask & kmask;
-                const int pos = __builtin_popcountll(le);        // entries that stay in front (<=: earlier index wins ties)
-                const float ud = __shfl_up(ld, 1, G);
-                const int ui = __shfl_up(li, 1, G);
-                if (act) {
-                    if (g > pos) {
-                        ld = ud;
-                        li = ui;
-                    } else if (g == pos) {
-                        ld = cd;
-                        li = ci;
-                    }
-                }
-                worst = __shfl(ld, gbase + K - 1, 64);
-                pass = pass && !(act && g == src) && d < worst;
-                bal = __ballot(pass);
-            }
-        }
-    }
-    if (valid && g < K) {
-        int32_t* out_i = job.idx + ((long long)b * Q + q) * K;
-        out_i[g] = li == IDX_EMPTY ? 0 : li;
-        if (job.d2) job.d2[((long long)b * Q + q) * K + g] = isinf(ld) ? 3.402823466e+38f : ld;
-    }
+    knn_group_body<G>(tab.jobs[j], bid - tab.jobs[j].block_begin, tile);
 }
 
 int kmax_class(int K)
@@ -294,7 +304,7 @@ int group_class(int K) { return K <= 16 ? 16 : 32; }
 // per-lane-list kernel, which splits ONE query's support over up to 64 lanes.
 bool use_group_kernel(const gdm_knn_job& j, int B)
 {
-    if (knn_kernel_version() != 2 || j.K < 2) return false;
+    if (knn_kernel_version() != 2 || j.K < 2) return false;   // separate-launch form only in mode 2
     return (long)B * j.Q >= 4096 || j.S <= 512;
 }
 
@@ -334,7 +344,9 @@ int launch_group(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
 int knn_kernel_version()
 {
     const char* e = getenv("GDM_KNN_KERNEL");
-    return (e && e[0] == '2') ? 2 : 1;
+    if (e && e[0] == '1') return 1;
+    if (e && e[0] == '2') return 2;
+    return 3;                                          // 3 = both bodies in one launch per K class
 }
 
 template <int KMAX>
@@ -345,6 +357,22 @@ int launch_class(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     tab.B = B;
     int nblocks = 0;
     for (int i = 0; i < njobs; ++i) {
+        const bool mixed = knn_kernel_version() == 3 && (KMAX == 16 || KMAX == 32) && jobs[i].K >= 2 &&
+                           ((long)B * jobs[i].Q >= 4096 || jobs[i].S <= 512) && group_class(jobs[i].K) == KMAX;
+        if (mixed) {
+            KnnJobDev& d = tab.jobs[tab.njobs++];
+            d.support = jobs[i].support; d.query = jobs[i].query; d.idx = jobs[i].idx; d.d2 = jobs[i].d2;
+            d.support_bstride = jobs[i].support_bstride; d.query_bstride = jobs[i].query_bstride;
+            d.S = jobs[i].S; d.Q = jobs[i].Q; d.K = jobs[i].K;
+            d.logT = -1;
+            d.blocks_per_b = gdm_cdiv(d.Q, KNN_BLOCK / KMAX);
+            d.block_begin = nblocks;
+            nblocks += d.blocks_per_b * B;
+            continue;
+        }
+        if (knn_kernel_version() == 3 && jobs[i].K >= 2 && kmax_class(jobs[i].K) != group_class(jobs[i].K) &&
+            ((long)B * jobs[i].Q >= 4096 || jobs[i].S <= 512))
+            continue;                                  // K <= 8 query-rich job: served by the KMAX=16 launch below
         if (kmax_class(jobs[i].K) != KMAX || use_group_kernel(jobs[i], B)) continue;
         KnnJobDev& d = tab.jobs[tab.njobs++];
         d.support = jobs[i].support;
