@@ -82,36 +82,45 @@ __device__ __forceinline__ void knn_group_body(const KnnJobDev& job, int local, 
     float ld = INFINITY;                             // this lane's list element
     int li = IDX_EMPTY;
     float worst = INFINITY;                          // list[K-1], identical in all lanes of the group
+    int worst_i = IDX_EMPTY;
 
-    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
+    // Tile t holds the support points t, t + ntiles, t + 2 ntiles, ...: every tile is a uniform subsample of the
+    // whole set.  Support sets here are often pixel grids in raster order; scanned in that order the distance to a
+    // query falls monotonically for half the scan and nearly every point would be inserted.  With subsampled tiles
+    // the K-th distance is tight after the first tile.  Order is then not index order, so ties are resolved by an
+    // explicit (d2, index) comparison.
+    const int ntiles = (S + KNN_TILE - 1) / KNN_TILE;
+    for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        const int npt = min(KNN_TILE, S - tile0);
         for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
+            const int gi = p * ntiles + t;
             float4 v;
-            if (p < npt) {
-                const float* s3 = sup + (long long)(tile0 + p) * 3;
-                v = make_float4(s3[0], s3[1], s3[2], 0.f);
+            if (gi < S) {
+                const float* s3 = sup + (long long)gi * 3;
+                v = make_float4(s3[0], s3[1], s3[2], __int_as_float(gi));
             } else {
-                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+                v = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(IDX_EMPTY));
             }
             tile[p] = v;
         }
         __syncthreads();
+        const int npt = (S - t + ntiles - 1) / ntiles;               // valid slots in this tile
         const int steps = (npt + G - 1) / G;
         for (int s = 0; s < steps; ++s) {
-            const int p = s * G + g;
-            const float4 v = tile[p];
+            const float4 v = tile[s * G + g];
             const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
-            bool pass = d < worst;                   // strict: equal distance, higher index -> rejected
+            const int di = __float_as_int(v.w);
+            bool pass = d < worst || (d == worst && di < worst_i);
             unsigned long long bal = __ballot(pass);
             while (bal) {                            // wave-uniform loop
                 const unsigned long long m = (bal >> gbase) & gmask;
                 const bool act = m != 0ull;          // group-uniform
                 const int src = act ? __builtin_ctzll(m) : 0;
                 const float cd = __shfl(d, gbase + src, 64);
-                const int ci = tile0 + s * G + src;
-                const unsigned long long le = (__ballot(ld <= cd) >> gbase) & gmask & kmask;
-                const int pos = __builtin_popcountll(le);        // entries that stay in front (<=: earlier index wins ties)
+                const int ci = __shfl(di, gbase + src, 64);
+                const bool before = ld < cd || (ld == cd && li < ci);
+                const unsigned long long le = (__ballot(before) >> gbase) & gmask & kmask;
+                const int pos = __builtin_popcountll(le);        // entries that stay in front of the candidate
                 const float ud = __shfl_up(ld, 1, G);
                 const int ui = __shfl_up(li, 1, G);
                 if (act) {
@@ -124,7 +133,8 @@ __device__ __forceinline__ void knn_group_body(const KnnJobDev& job, int local, 
                     }
                 }
                 worst = __shfl(ld, gbase + K - 1, 64);
-                pass = pass && !(act && g == src) && d < worst;
+                worst_i = __shfl(li, gbase + K - 1, 64);
+                pass = pass && !(act && g == src) && (d < worst || (d == worst && di < worst_i));
                 bal = __ballot(pass);
             }
         }
@@ -135,7 +145,6 @@ __device__ __forceinline__ void knn_group_body(const KnnJobDev& job, int local, 
         if (job.d2) job.d2[((long long)b * Q + q) * K + g] = isinf(ld) ? 3.402823466e+38f : ld;
     }
 }
-
 
 template <int KMAX>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
