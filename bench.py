@@ -196,26 +196,27 @@ def main():
                       "algorithmic_tflops": round(flops / (match_ms * 1e-3) / 1e12, 2),
                       "avg_ms": round(match_ms, 4), "traffic": None}
     _ = fused_bytes
+    mat_ms = float("nan")
     with torch.no_grad():
-        ep_rgbd, ep_mesh = None, None
         d = dict(inputs)
         d.update(pyramid.build_pyramid(cld, dpt_xyz))
         ep = model(d)
         srows = ops.match_pack(ep["rgbd"], prec)
         mrows = ops.match_pack(ep["mesh"][0], prec)
-        sim = torch.empty((B, N, M), dtype=torch.float32, device=dev)
-        for _ in range(3):
+        sim = torch.empty((B, N, M), dtype=torch.float32, device=dev) if rank == 0 else None
+        for _ in range(3 if rank == 0 else 0):
             ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
         torch.cuda.synchronize()
         evs = []
-        for _ in range(max(args.steps, 10)):
+        for _ in range(max(args.steps, 10) if rank == 0 else 0):
             a, b = ev(), ev()
             a.record()
             ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize()
-        mat_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        if evs:
+            mat_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         del sim
     # PMC traffic comes from separate rocprofv3 --pmc passes (profiles/match_traffic.json), valid for the
     # headline shape only
