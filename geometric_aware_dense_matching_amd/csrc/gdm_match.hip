@@ -282,7 +282,6 @@ constexpr int PANEL_COLS = 256;
 constexpr int PANEL_BYTES = PANEL_COLS * ROW_BYTES;     // 128 KiB
 constexpr int V2_THREADS = 512;
 constexpr int V2_ROWS = 256;                            // scene rows per workgroup iteration
-constexpr int V2_STAGE_BYTES = (V2_THREADS / 64) * 4096; // per-wave 32x32 fp32 store-staging tiles (WRITE_SIM only)
 
 template <int PREC>
 __device__ __forceinline__ void load_a_rows(const unsigned char* __restrict__ apk, int row, int R, int h, u32x4 (&a)[16])
@@ -297,7 +296,7 @@ __device__ __forceinline__ void load_a_rows(const unsigned char* __restrict__ ap
     }
 }
 
-template <int PREC, bool WRITE_SIM, int DIAG = 0>     // DIAG 1: no MFMAs (store path alone), timing builds only
+template <int PREC, bool WRITE_SIM>
 __global__ __launch_bounds__(V2_THREADS) void match_panel_kernel(const unsigned char* __restrict__ apk,
                                                                   const unsigned char* __restrict__ bpk,
                                                                   int R, int M, int G,
@@ -356,13 +355,7 @@ __global__ __launch_bounds__(V2_THREADS) void match_panel_kernel(const unsigned 
                 acc1[i] = 0.f;
             }
             const int c0 = cp * 64 + lr, c1 = c0 + 32;
-            if (DIAG == 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    acc0[i] = __uint_as_float(areg[i].x);
-                    acc1[i] = __uint_as_float(areg[i].y);
-                }
-            } else if (PREC == GDM_MATCH_BF16X3) {
+            if (PREC == GDM_MATCH_BF16X3) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 2 * s + h)));
@@ -406,34 +399,12 @@ __global__ __launch_bounds__(V2_THREADS) void match_panel_kernel(const unsigned 
                     best[reg] = v1;
                     bidx[reg] = gc1;
                 }
-            }
-            if (WRITE_SIM) {
-                // Tile store through a per-wave 32x32 LDS staging tile: the accumulator layout gives each lane one
-                // column (4-B stores, 16 instructions per tile); transposed through LDS every lane owns 16 contiguous
-                // bytes of a row, so a tile leaves in 4 wide store instructions (8 rows x 128 B each).  Same-wave
-                // LDS write -> read needs no barrier (in-order LDS pipeline).
-                float* stg = reinterpret_cast<float*>(smem + PANEL_BYTES) + wave * 1024;
-                const bool full = (col0 + cp * 64 + 64 <= M) && (row0 + 32 <= R) && ((M & 3) == 0);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const f32x16& acc = half ? acc1 : acc0;
-                    const int gcb = col0 + cp * 64 + half * 32;            // first global column of this 32x32 tile
-                    if (full) {
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) stg[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + lr] = acc[reg];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int rr = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * 32 + c4);
-                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(sim + (long)(row0 + rr) * M + gcb + c4));
-                        }
-                    } else {                                               // ragged edge: per-element stores with bounds checks
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                            if (grow < R && gcb + lr < M && (cp * 64 + half * 32 + lr) < ncols)
-                                __builtin_nontemporal_store(acc[reg], sim + (long)grow * M + gcb + lr);
-                        }
+                if (WRITE_SIM) {
+                    const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (grow < R) {
+                        float* o = sim + (long)grow * M;
+                        if (ok0) __builtin_nontemporal_store(v0, o + gc0);
+                        if (ok1) __builtin_nontemporal_store(v1, o + gc1);
                     }
                 }
             }
@@ -634,18 +605,14 @@ extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_ro
         int32_t* oi = nsplit == 1 ? best_idx : pidx;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES + V2_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
             (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
-            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES + V2_STAGE_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
             (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
-            (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES + V2_STAGE_BYTES);
             attr_set = true;
         }
-#define LAUNCH2(P, W) hipLaunchKernelGGL((match_panel_kernel<P, W>), grid, dim3(V2_THREADS), (W) ? PANEL_BYTES + V2_STAGE_BYTES : PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi)
-        const char* diag = getenv("GDM_MATCH_DIAG");
-        if (diag && diag[0] == '1' && ws_sim && precision == GDM_MATCH_BF16X3) {
-            hipLaunchKernelGGL((match_panel_kernel<GDM_MATCH_BF16X3, true, 1>), grid, dim3(V2_THREADS), PANEL_BYTES + V2_STAGE_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi);
-        } else if (precision == GDM_MATCH_BF16X3) {
+#define LAUNCH2(P, W) hipLaunchKernelGGL((match_panel_kernel<P, W>), grid, dim3(V2_THREADS), PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi)
+        if (precision == GDM_MATCH_BF16X3) {
             if (ws_sim) LAUNCH2(GDM_MATCH_BF16X3, true); else LAUNCH2(GDM_MATCH_BF16X3, false);
         } else {
             if (ws_sim) LAUNCH2(GDM_MATCH_F32, true); else LAUNCH2(GDM_MATCH_F32, false);
