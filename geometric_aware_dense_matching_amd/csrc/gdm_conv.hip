@@ -1,0 +1,283 @@
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on split-bf16 MFMA, gfx950.
+//
+// For the 32x32-resolution half of the ResNet-18 trunk (layer3 / layer4 of
+// /root/reference/models/cnn/extractors.py:36-58,151-177: 128..512 -> 256..512 channels), where MIOpen's
+// fp32 path is an ASM Winograd F(2,3) kernel on the vector ALUs (~118 TF/s direct-equivalent).  fp32 products are
+// replaced by three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; |err| <= 3*2^-18 per product, the same
+// scheme as the descriptor matching kernel), which is ~5x the f32-MFMA rate.
+//
+//   out[b,co,y,x] = act( scale[co] * sum_{tap,ci} W[co,ci,tap] * in[b,ci,y+ky-1,x+kx-1] + shift[co] (+ res) )
+//
+// Data layout: activations are re-packed once per layer (pack kernel below) into PIXEL-major rows with a one-pixel
+// zero border: row((b,yy,xx), chunk) = 128 bf16 hi | 128 bf16 lo of channels [128 chunk, 128 chunk + 128), so a tap
+// is just a row offset and the zero padding is real zeros.  Weights are packed once per weight change into
+// rows (tap, chunk, co) of the same 512-B format.  Then the kernel is the matching kernel's shape: a wave keeps
+// 32 pixels x 128 channels of one (tap, chunk) in 64 VGPRs as the MFMA A operand, 128 output channels of that
+// (tap, chunk) sit in a double-buffered, XOR-swizzled LDS panel as the B operand (global -> registers before the
+// MFMAs, registers -> LDS after them, ONE barrier per panel), 9 * Cin/128 panels accumulate into four 32x32 tiles.
+#include "gdm_common.h"
+#include <math.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int ROWB = 512;                 // bytes per packed row (128 channels, hi | lo)
+constexpr int CV_THREADS = 512;           // 8 waves
+constexpr int CV_PIX = 256;               // pixels per workgroup (32 per wave)
+constexpr int CV_CO = 128;                // output channels per workgroup
+constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
+
+__device__ __forceinline__ unsigned short bf16_rne(float v)
+{
+    unsigned u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__device__ __forceinline__ void split8(const float* v, unsigned (&hi)[4], unsigned (&lo)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short h0 = bf16_rne(v[2 * j]), h1 = bf16_rne(v[2 * j + 1]);
+        const unsigned short l0 = bf16_rne(v[2 * j] - bf16_f32(h0)), l1 = bf16_rne(v[2 * j + 1] - bf16_f32(h1));
+        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+}
+
+// x f32[B,C,H,W] -> packed rows of the zero-bordered pixel grid: row = ((b*(H+2) + y+1)*(W+2) + x+1)*nchunk + chunk
+// one block: 64 consecutive pixels of one image row-major plane index x one 128-channel chunk
+__global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restrict__ x, int C, int H, int W,
+                                                            unsigned char* __restrict__ out)
+{
+    __shared__ float t[128][65];
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int nchunk = C / 128;
+    const int hw = H * W;
+    const int p0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = min(p0 + lane, hw - 1);
+    const float* xb = x + ((long)b * C + chunk * 128) * hw;
+    for (int c = w; c < 128; c += 4) t[c][lane] = xb[(long)c * hw + p];
+    __syncthreads();
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * 256 + threadIdx.x;        // 64 pixels x 16 chunks of 8 channels
+        const int ch = item & 15, pl = item >> 4;
+        if (p0 + pl >= hw) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = t[ch * 8 + j][pl];
+        unsigned hi[4], lo[4];
+        split8(v, hi, lo);
+        const int pp = p0 + pl, y = pp / W, xx = pp - y * W;
+        unsigned char* row = out + ((((long)b * (H + 2) + y + 1) * (W + 2) + xx + 1) * nchunk + chunk) * ROWB;
+        *reinterpret_cast<uint4*>(row + ch * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(row + 256 + ch * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+// w f32[Cout,Cin,3,3] -> rows ((tap*nchunk + chunk)*Cout + co): channels [128 chunk, +128) of tap (ky,kx)
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned char* __restrict__ out)
+{
+    const int nchunk = Cin / 128;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 16 groups of 8 channels)
+    const long rows = 9L * nchunk * Cout;
+    if (item >= rows * 16) return;
+    const int ch = (int)(item & 15);
+    const long row = item >> 4;
+    const int co = (int)(row % Cout);
+    const int tc = (int)(row / Cout);
+    const int chunk = tc % nchunk, tap = tc / nchunk;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[((long)co * Cin + chunk * 128 + ch * 8 + j) * 9 + tap];
+    unsigned hi[4], lo[4];
+    split8(v, hi, lo);
+    unsigned char* r = out + row * ROWB;
+    *reinterpret_cast<uint4*>(r + ch * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(r + 256 + ch * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__device__ __forceinline__ int swz(int col, int ch) { return col * ROWB + (((ch & 16) | ((ch ^ col) & 15)) << 4); }
+
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
+                                                                    float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, h = lane >> 5;
+    const int nchunk = Cin / 128;
+    const int npanel = 9 * nchunk;
+    const int hw = H * W;
+    const long ptot = (long)B * hw;
+    const long pix0 = (long)blockIdx.x * CV_PIX + wave * 32;       // this wave's first pixel (32 consecutive, same image row: W % 32 == 0)
+    const int co0 = blockIdx.y * CV_CO;
+    const long pc = min(pix0, ptot - 32);
+    const int b = (int)(pc / hw);
+    const int prem = (int)(pc - (long)b * hw);
+    const int y = prem / W, x0 = prem - y * W;
+    // packed row of (b, y, x0 + lr) for tap (0,0): padded coords (y + ky, x + kx), ky,kx in 0..2
+    const long rowbase = (((long)b * (H + 2) + y) * (W + 2) + x0 + lr) * nchunk;
+
+    // A operand in two halves of the 128-channel chunk (k-steps 0-3 / 4-7): a half's registers are reloaded with the
+    // NEXT panel's data as soon as the current panel is done with them, so the prefetch needs no second register set
+    // (64 + 64 VGPRs would not fit beside the accumulators at 2 waves per SIMD).
+    u32x4 ahi[8], alo[8];                                           // fragments of k-step s: ahi[s], alo[s]
+    auto load_a_half = [&](int it, int half) {
+        const int tap = it / nchunk, chunk = it - tap * nchunk;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char* r = xpk + (rowbase + ((long)ky * (W + 2) + kx) * nchunk + chunk) * ROWB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ss = half * 4 + s;
+            ahi[ss] = *reinterpret_cast<const u32x4*>(r + (2 * ss + h) * 16);
+            alo[ss] = *reinterpret_cast<const u32x4*>(r + (16 + 2 * ss + h) * 16);
+        }
+    };
+    u32x4 stage[8];
+    auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
+        const unsigned char* src = wpk + ((long)it * Cout + co0) * ROWB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = i * CV_THREADS + tid;
+            stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char* base = smem + buf * CV_PANEL;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = i * CV_THREADS + tid;
+            *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    stage_load(0);
+    stage_store(0);
+    load_a_half(0, 0);
+    load_a_half(0, 1);
+    for (int it = 0; it < npanel; ++it) {
+        __syncthreads();                                            // panel `it` is in LDS; panel it-1's readers are done
+        const bool more = it + 1 < npanel;
+        if (more) stage_load(it + 1);
+        const unsigned char* base = smem + (it & 1) * CV_PANEL;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int col = cb * 32 + lr;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int s = half * 4 + s4;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + swz(col, 2 * s + h)));
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + swz(col, 16 + 2 * s + h)));
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[s]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, alo[s]);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
+                }
+            }
+            if (more) load_a_half(it + 1, half);                    // this half's registers are free now
+        }
+        if (more) stage_store((it + 1) & 1);
+    }
+
+    // ---- epilogue: lane = output channel (col), registers = pixels; 4 consecutive pixels per register quad -> 16-B stores ----
+    if (pix0 >= ptot) return;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int co = co0 + cb * 32 + lr;
+        if (co >= Cout) continue;
+        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+        float* op = out + ((long)b * Cout + co) * hw + prem;
+        const float* rp = HAS_RES ? res + ((long)b * Cout + co) * hw + prem : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int poff = 8 * g + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[cb][4 * g + j] * sc + sh;
+            if (HAS_RES) {
+                const float4 r4 = *reinterpret_cast<const float4*>(rp + poff);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            if (ACT == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W)
+{
+    if (B < 1 || Cin < 128 || Cin % 128 || H < 1 || W < 1) return 0;
+    return (size_t)B * (H + 2) * (W + 2) * (Cin / 128) * ROWB;
+}
+
+extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
+{
+    if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
+    return (size_t)9 * (Cin / 128) * Cout * ROWB;
+}
+
+extern "C" int gdm_conv3x3_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream)
+{
+    GDM_CHECK_ARG(w && wpk, "gdm_conv3x3_pack_weight_hip: NULL pointer");
+    GDM_CHECK_ARG(Cout >= 1 && Cin >= 128 && Cin % 128 == 0, "gdm_conv3x3_pack_weight_hip: Cout=%d Cin=%d (Cin %% 128 == 0)", Cout, Cin);
+    const long items = 9L * (Cin / 128) * Cout * 16;
+    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, (unsigned char*)wpk);
+    return gdm_launch_status("conv_pack_w_kernel");
+}
+
+// xpk must be zero-filled by the caller (the border rows are never written).
+extern "C" int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, int W, void* xpk, void* stream)
+{
+    GDM_CHECK_ARG(x && xpk, "gdm_conv3x3_pack_act_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && Cin >= 128 && Cin % 128 == 0 && H >= 1 && W >= 1, "gdm_conv3x3_pack_act_hip: bad shape");
+    dim3 grid(gdm_cdiv((long)H * W, 64), Cin / 128, B);
+    hipLaunchKernelGGL(conv_pack_act_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, H, W, (unsigned char*)xpk);
+    return gdm_launch_status("conv_pack_act_kernel");
+}
+
+extern "C" int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                                      int B, int Cin, int Cout, int H, int W, int act, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv3x3_packed_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && ((long)B * H * W) % 32 == 0, "gdm_conv3x3_packed_hip: W=%d must be a multiple of 32", W);
+    GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv3x3_packed_hip: act=%d", act);
+    const long ptot = (long)B * H * W;
+    dim3 grid(gdm_cdiv(ptot, CV_PIX), Cout / CV_CO);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        attr = true;
+    }
+#define CV(A, R) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, R>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out)
+    if (act == 0) { if (res) CV(0, true); else CV(0, false); }
+    else { if (res) CV(1, true); else CV(1, false); }
+#undef CV
+    return gdm_launch_status("conv3x3_bf16x3_kernel");
+}

@@ -397,6 +397,47 @@ def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     return x
 
 
+_conv_act_cache = {}
+
+
+def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1)):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1)
+            and weight.shape[1] % 128 == 0 and weight.shape[0] % 128 == 0 and x.shape[3] % 32 == 0 and x.shape[0] <= 65535)
+
+
+def conv3x3_pack_weight(weight):
+    """w f32[Cout,Cin,3,3] -> packed split-bf16 rows (u8 tensor); cache it per weight version."""
+    weight = _dev(weight.detach(), torch.float32, "weight")
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    L = _lib.lib()
+    wpk = torch.empty(L.gdm_conv3x3_weight_bytes(Cout, Cin), dtype=torch.uint8, device=weight.device)
+    check(L.gdm_conv3x3_pack_weight_hip(weight.data_ptr(), Cout, Cin, wpk.data_ptr(), _stream()), "gdm_conv3x3_pack_weight_hip")
+    return wpk
+
+
+def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None):
+    """3x3/s1/p1 convolution of x f32[B,Cin,H,W] with packed weights on split-bf16 MFMA (+ per-channel scale/shift,
+    optional residual, optional ReLU).  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, Cin, H, W = x.shape
+    L = _lib.lib()
+    key = (B, Cin, H, W, x.device.index, torch.cuda.current_stream().cuda_stream)
+    xpk = _conv_act_cache.get(key)
+    if xpk is None:
+        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(B, Cin, H, W), dtype=torch.uint8, device=x.device)   # zero border, kept
+        _conv_act_cache[key] = xpk
+    check(L.gdm_conv3x3_pack_act_hip(x.data_ptr(), B, Cin, H, W, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    if res is not None:
+        res = _dev(res, torch.float32, "res")
+        assert res.shape == out.shape
+    check(L.gdm_conv3x3_packed_hip(xpk.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                   shift.data_ptr() if shift is not None else None, res.data_ptr() if res is not None else None,
+                                   B, Cin, cout, H, W, act, out.data_ptr(), _stream()), "gdm_conv3x3_packed_hip")
+    return out
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

@@ -229,6 +229,21 @@ int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2
 int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
                                   int B, int C, int n, int m, int act, float slope, float* y, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate),
+ * for the 32x32-resolution ResNet-18 layers (models/cnn/extractors.py:36-58,151-177) where MIOpen's fp32 path is a
+ * vector-ALU Winograd kernel.  Cin, Cout multiples of 128, W a multiple of 32.
+ *   pack_weight: w f32[Cout,Cin,3,3] -> wpk (gdm_conv3x3_weight_bytes), once per weight change
+ *   pack_act   : x f32[B,Cin,H,W]    -> xpk (gdm_conv3x3_act_bytes; pixel-major rows with a one-pixel ZERO border: the
+ *                caller provides a zero-filled buffer, only interior rows are written)
+ *   packed     : out f32[B,Cout,H,W] = act(scale[co] * conv + shift[co] (+ res)), act 0 none / 1 ReLU; scale/shift/res may be NULL */
+size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W);
+size_t gdm_conv3x3_weight_bytes(int Cout, int Cin);
+int gdm_conv3x3_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream);
+int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, int W, void* xpk, void* stream);
+int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                           int B, int Cin, int Cout, int H, int W, int act, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

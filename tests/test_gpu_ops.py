@@ -316,3 +316,25 @@ def test_upconv3x3_gather_equals_conv_after_upsample(ops, B, Cin, Cout, H, W):
     z = torch.nn.functional.conv2d(x.cuda(), wt.cuda())
     got = ops.upconv3x3_gather(z, scale.cuda(), shift.cuda(), Cout, (2 * H, 2 * W), ops.ACT_LEAKY, 0.25).cpu()
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 32, 32), (1, 256, 512, 32, 32), (3, 512, 128, 8, 32), (2, 128, 256, 5, 64)])
+def test_conv3x3_bf16x3_vs_fp32_conv(ops, B, Cin, Cout, H, W):
+    """Split-bf16 MFMA implicit GEMM vs the fp64 convolution on the CPU; error bound 3*2^-18 * sum|w x| per output
+    (measured ~1e-6 relative to the output scale), far inside the network tolerance used against the golden vectors."""
+    rs = np.random.RandomState(Cin + Cout + H)
+    x = torch.from_numpy(rs.randn(B, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(np.float32))
+    scale = torch.from_numpy((1 + 0.1 * rs.randn(Cout)).astype(np.float32))
+    shift = torch.from_numpy((0.1 * rs.randn(Cout)).astype(np.float32))
+    res = torch.from_numpy(rs.randn(B, Cout, H, W).astype(np.float32))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    wpk = ops.conv3x3_pack_weight(w.cuda())
+    got = ops.conv3x3_bf16x3(x.cuda(), wpk, Cout).cpu()
+    assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    want2 = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    got2 = ops.conv3x3_bf16x3(x.cuda(), wpk, Cout, scale.cuda(), shift.cuda(), ops.ACT_RELU, res.cuda()).cpu()
+    assert (got2.double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item())
+    # a second call reuses the cached zero-bordered buffer: borders must still be zero
+    got3 = ops.conv3x3_bf16x3(x.cuda(), wpk, Cout).cpu()
+    assert torch.equal(got, got3)
