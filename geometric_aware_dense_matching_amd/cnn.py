@@ -15,6 +15,7 @@ Behaviour worth knowing (all reproduced):
     network at construction, pspnet.py:141 -> extractors.py:203-212).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -22,6 +23,10 @@ import torch.nn.functional as F
 
 from . import ops
 from .layers import act_code, folded_bn, fused_eval
+
+
+# GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
+USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
 
 
 def _conv3x3(cin, cout, stride=1, dilation=1):
@@ -38,7 +43,35 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
+    @staticmethod
+    def _packed_weight(conv):
+        w = conv.weight
+        key = (w._version, w.data_ptr())
+        cache = conv.__dict__.get("_gdm_wpk")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.conv3x3_pack_weight(w))
+            conv.__dict__["_gdm_wpk"] = cache
+        return cache[1]
+
+    def _mfma_ok(self, x):
+        return (USE_MFMA_CONV and ops.conv3x3_supported(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation)
+                and ops.conv3x3_supported(x, self.conv2.weight, self.conv2.stride, self.conv2.padding, self.conv2.dilation)
+                and self.conv2.weight.shape[1] == self.conv1.weight.shape[0])
+
     def forward(self, x):
+        if fused_eval(x, self) and self._mfma_ok(x):
+            # layer3 / layer4 at 32x32: both 3x3 convolutions on the split-bf16 MFMA implicit-GEMM kernel with BN, ReLU and
+            # the residual add in its epilogue (MIOpen's fp32 path here is a vector-ALU Winograd kernel, 2.7x slower)
+            s1, b1 = folded_bn(self.bn1)
+            planes = self.conv1.weight.shape[0]
+            out = ops.conv3x3_bf16x3(x, self._packed_weight(self.conv1), planes, s1, b1, ops.ACT_RELU)
+            s2, b2 = folded_bn(self.bn2)
+            if self.downsample is None:
+                res = x
+            else:
+                sd, bd = folded_bn(self.downsample[1])
+                res = ops.affine_act(self.downsample[0](x), sd, bd, ops.ACT_NONE)
+            return ops.conv3x3_bf16x3(out, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res)
         if fused_eval(x, self):
             # eval: conv -> [BN+ReLU] -> conv -> [BN + (BN'd) residual + ReLU], each bracket one HIP launch
             s1, b1 = folded_bn(self.bn1)
