@@ -155,9 +155,11 @@ class PSPModule(nn.Module):
             ms, wf = self._split_weights()
             B, Cin = feats.shape[0], feats.shape[1]
             g = torch.matmul(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
+            sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
+            pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and 36 <= h * w <= 4096 and h >= 6 and w >= 6 else None
             ys = []
-            for st, m in zip(self.stages, ms):
-                p = st[0](feats)                                            # adaptive average pool to s x s
+            for k, (st, m) in enumerate(zip(self.stages, ms)):
+                p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
                 s_ = p.shape[2]
                 ys.append(torch.matmul(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
             return ops.psp_combine(g, ys, self.bottleneck.bias)
@@ -204,6 +206,16 @@ class PSPUpsample(nn.Module):
         return self.conv(x)
 
 
+class FinalStage(nn.Sequential):
+    """Conv2d(64,64,1) + LogSoftmax(dim=1) (pspnet.py:108-112; same child names "0", "1"): one HIP pass in eval."""
+
+    def forward(self, x):
+        conv = self[0]
+        if fused_eval(x, self) and conv.in_channels == 64 and conv.out_channels == 64 and x.shape[0] <= 65535:
+            return ops.conv1x1_logsoftmax(x, conv.weight, conv.bias)
+        return nn.Sequential.forward(self, x)
+
+
 class PSPNet(nn.Module):
     """pspnet.py:93-121 with the resnet18 settings of `psp_models['resnet18']` (:141); only the
     sub-modules FFB6DEmb borrows are used, the rest exists for checkpoint key parity."""
@@ -217,4 +229,4 @@ class PSPNet(nn.Module):
         self.up_2 = PSPUpsample(256, 64)
         self.up_3 = PSPUpsample(64, 64)
         self.drop_2 = nn.Dropout2d(p=0.15)
-        self.final = nn.Sequential(nn.Conv2d(64, 64, kernel_size=1), nn.LogSoftmax(dim=1))
+        self.final = FinalStage(nn.Conv2d(64, 64, kernel_size=1), nn.LogSoftmax(dim=1))

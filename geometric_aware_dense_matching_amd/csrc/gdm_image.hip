@@ -340,6 +340,70 @@ __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float*
     }
 }
 
+// `final` = Conv2d(64,64,1) + LogSoftmax(dim=1) (pspnet.py:108-112), applied at 128x128 and 256x256 (ffb6d.py:79-80):
+// one pass instead of a GEMM + bias + spatial-softmax (313 + 136 us at 256x256, batch 16).  HBM-bound (read C, write C
+// floats per pixel); a thread owns one pixel, keeps the C output channels in registers, weights arrive as wave-uniform
+// scalar loads, log-softmax stays in-thread.  Exact fp32 FMAs.
+template <int C>
+__global__ __launch_bounds__(256) void conv1x1_logsoftmax_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, long hw, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float* xb = x + (long)b * C * hw + p;
+    float y[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) y[co] = bias ? bias[co] : 0.f;
+#pragma unroll 4
+    for (int ci = 0; ci < C; ++ci) {
+        const float xv = xb[(long)ci * hw];
+#pragma unroll
+        for (int co = 0; co < C; ++co) y[co] = fmaf(w[co * C + ci], xv, y[co]);
+    }
+    float m = y[0];
+#pragma unroll
+    for (int co = 1; co < C; ++co) m = fmaxf(m, y[co]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int co = 0; co < C; ++co) ssum += expf(y[co] - m);
+    const float lse = m + logf(ssum);
+    float* ob = out + (long)b * C * hw + p;
+#pragma unroll
+    for (int co = 0; co < C; ++co) ob[(long)co * hw] = y[co] - lse;
+}
+
+// The four adaptive average pools of the pyramid-pooling module (1,2,3,6 bins; pspnet.py:17-20) in one pass over the
+// feature map: one workgroup per plane accumulates the 6x6-bin... every bin size separately with PyTorch's bin edges
+// (start = floor(i*H/s), end = ceil((i+1)*H/s)); outputs f32[planes, s*s] each.
+__global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict__ x, int H, int W,
+                                                        float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3,
+                                                        float* __restrict__ o6)
+{
+    __shared__ float tile[64 * 64];
+    const long plane = blockIdx.x;
+    const int hw = H * W;
+    const float* xp = x + plane * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) tile[i] = xp[i];
+    __syncthreads();
+    // 1 + 4 + 9 + 36 = 50 bins; one thread per bin
+    const int t = threadIdx.x;
+    int s, bi;
+    float* o;
+    if (t < 1) { s = 1; bi = t; o = o1 + plane; }
+    else if (t < 5) { s = 2; bi = t - 1; o = o2 + plane * 4; }
+    else if (t < 14) { s = 3; bi = t - 5; o = o3 + plane * 9; }
+    else if (t < 50) { s = 6; bi = t - 14; o = o6 + plane * 36; }
+    else return;
+    const int by = bi / s, bx = bi - by * s;
+    const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
+    const int x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
+    float acc = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) acc += tile[yy * W + xx];
+    o[bi] = acc / (float)((y1 - y0) * (x1 - x0));
+}
+
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -445,4 +509,21 @@ extern "C" int gdm_gather_add_affine_act_hip(const float* x, const float* t, con
     else if (act == 1) hipLaunchKernelGGL(gather_add_affine_act_kernel<1>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
     else hipLaunchKernelGGL(gather_add_affine_act_kernel<2>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
     return gdm_launch_status("gather_add_affine_act_kernel");
+}
+
+extern "C" int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream)
+{
+    GDM_CHECK_ARG(x && w && out, "gdm_conv1x1_logsoftmax_hip: NULL pointer");
+    GDM_CHECK_ARG(C == 64, "gdm_conv1x1_logsoftmax_hip: C=%d, only the 64-channel `final` stage is built", C);
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && hw >= 1, "gdm_conv1x1_logsoftmax_hip: bad shape");
+    hipLaunchKernelGGL(conv1x1_logsoftmax_kernel<64>, dim3(gdm_cdiv(hw, 256), B), dim3(256), 0, (hipStream_t)stream, x, w, bias, hw, out);
+    return gdm_launch_status("conv1x1_logsoftmax_kernel");
+}
+
+extern "C" int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, float* o2, float* o3, float* o6, void* stream)
+{
+    GDM_CHECK_ARG(x && o1 && o2 && o3 && o6, "gdm_psp_pools_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && H >= 6 && W >= 6 && H * W <= 64 * 64, "gdm_psp_pools_hip: map %dx%d must be between 6x6 and 64x64 pixels", H, W);
+    hipLaunchKernelGGL(psp_pools_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, H, W, o1, o2, o3, o6);
+    return gdm_launch_status("psp_pools_kernel");
 }

@@ -397,6 +397,27 @@ def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     return x
 
 
+def conv1x1_logsoftmax(x, weight, bias):
+    """log_softmax over channels of a 64->64 1x1 convolution, one pass (the `final` stage, pspnet.py:108-112). Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    w = _dev(weight.detach().reshape(C, C), torch.float32, "weight")
+    out = torch.empty_like(x)
+    check(_lib.lib().gdm_conv1x1_logsoftmax_hip(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                B, C, H * W, out.data_ptr(), _stream()), "gdm_conv1x1_logsoftmax_hip")
+    return out
+
+
+def psp_pools(x):
+    """Adaptive average pools to 1,2,3,6 bins in one pass: x f32[B,C,H,W] -> four f32[B,C,s,s]. Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    outs = [torch.empty((B, C, s_, s_), dtype=torch.float32, device=x.device) for s_ in (1, 2, 3, 6)]
+    check(_lib.lib().gdm_psp_pools_hip(x.data_ptr(), B * C, H, W, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                       outs[3].data_ptr(), _stream()), "gdm_psp_pools_hip")
+    return outs
+
+
 _conv_act_cache = {}
 
 

@@ -244,6 +244,12 @@ int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, int W, void*
 int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                            int B, int Cin, int Cout, int H, int W, int act, float* out, void* stream);
 
+/* `final` stage of the image branch (pspnet.py:108-112): out = log_softmax_c(W x + b), x,out f32[B,64,hw], W f32[64,64]. */
+int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream);
+/* The four adaptive average pools (1,2,3,6 bins) of the pyramid pooling module (pspnet.py:17-20) in one pass:
+ * x f32[planes,H,W] -> o1 f32[planes,1], o2 [planes,4], o3 [planes,9], o6 [planes,36] (PyTorch bin edges). */
+int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, float* o2, float* o3, float* o6, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

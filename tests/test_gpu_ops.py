@@ -338,3 +338,20 @@ def test_conv3x3_bf16x3_vs_fp32_conv(ops, B, Cin, Cout, H, W):
     # a second call reuses the cached zero-bordered buffer: borders must still be zero
     got3 = ops.conv3x3_bf16x3(x.cuda(), wpk, Cout).cpu()
     assert torch.equal(got, got3)
+
+
+def test_final_stage_and_psp_pools(ops):
+    rs = np.random.RandomState(12)
+    x = torch.from_numpy(rs.randn(2, 64, 40, 24).astype(np.float32))
+    w = torch.from_numpy((rs.randn(64, 64, 1, 1) / 8).astype(np.float32))
+    b = torch.from_numpy((0.1 * rs.randn(64)).astype(np.float32))
+    want = torch.log_softmax(torch.nn.functional.conv2d(x, w, b), dim=1)
+    got = ops.conv1x1_logsoftmax(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-5)
+    f = torch.from_numpy(rs.randn(3, 7, 32, 32).astype(np.float32))
+    outs = ops.psp_pools(f.cuda())
+    for s_, o in zip((1, 2, 3, 6), outs):
+        assert torch.allclose(o.cpu(), torch.nn.functional.adaptive_avg_pool2d(f, s_), rtol=1e-5, atol=1e-6)
+    f2 = torch.from_numpy(rs.randn(1, 3, 13, 9).astype(np.float32))                 # uneven bins
+    for s_, o in zip((1, 2, 3, 6), ops.psp_pools(f2.cuda())):
+        assert torch.allclose(o.cpu(), torch.nn.functional.adaptive_avg_pool2d(f2, s_), rtol=1e-5, atol=1e-6)
