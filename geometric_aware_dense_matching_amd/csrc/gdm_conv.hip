@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
 }
 
 // w f32[Cout,Cin,3,3] -> rows ((tap*nchunk + chunk)*Cout + co): channels [128 chunk, +128) of tap (ky,kx)
-__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned char* __restrict__ out)
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, unsigned char* __restrict__ out)
 {
     const int nchunk = Cin / 128;
     const long item = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 16 groups of 8 channels)
-    const long rows = 9L * nchunk * Cout;
+    const long rows = (long)taps * nchunk * Cout;
     if (item >= rows * 16) return;
     const int ch = (int)(item & 15);
     const long row = item >> 4;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
     const int chunk = tc % nchunk, tap = tc / nchunk;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = w[((long)co * Cin + chunk * 128 + ch * 8 + j) * 9 + tap];
+    for (int j = 0; j < 8; ++j) v[j] = w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap];
     unsigned hi[4], lo[4];
     split8(v, hi, lo);
     unsigned char* r = out + row * ROWB;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
 
 __device__ __forceinline__ int swz(int col, int ch) { return col * ROWB + (((ch & 16) | ((ch ^ col) & 15)) << 4); }
 
-template <int ACT, bool HAS_RES>
+template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false>   // TAPS 1 = 1x1 convolution / plain GEMM (centre tap only)
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, h = lane >> 5;
     const int nchunk = Cin / 128;
-    const int npanel = 9 * nchunk;
+    const int npanel = TAPS * nchunk;
     const int hw = H * W;
     const long ptot = (long)B * hw;
     const long pix0 = (long)blockIdx.x * CV_PIX + wave * 32;       // this wave's first pixel (32 consecutive, same image row: W % 32 == 0)
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     // (64 + 64 VGPRs would not fit beside the accumulators at 2 waves per SIMD).
     u32x4 ahi[8], alo[8];                                           // fragments of k-step s: ahi[s], alo[s]
     auto load_a_half = [&](int it, int half) {
-        const int tap = it / nchunk, chunk = it - tap * nchunk;
+        const int tap = (TAPS == 1) ? 4 : it / nchunk;
+        const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
         const int ky = tap / 3, kx = tap - ky * 3;
         const unsigned char* r = xpk + (rowbase + ((long)ky * (W + 2) + kx) * nchunk + chunk) * ROWB;
 #pragma unroll
@@ -198,6 +199,23 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 
     // ---- epilogue: lane = output channel (col), registers = pixels; 4 consecutive pixels per register quad -> 16-B stores ----
     if (pix0 >= ptot) return;
+    if (PIXMAJOR) {
+        // out[pixel][co]: for one register (pixel) the 32 lanes of a half-wave hold 32 consecutive channels = 128 B
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int co = co0 + cb * 32 + lr;
+            if (co >= Cout) continue;
+            const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long pix = pix0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float v = acc[cb][reg] * sc + sh;
+                if (ACT == 1) v = fmaxf(v, 0.f);
+                out[pix * Cout + co] = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int co = co0 + cb * 32 + lr;
@@ -238,13 +256,29 @@ extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
     return (size_t)9 * (Cin / 128) * Cout * ROWB;
 }
 
+extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
+{
+    if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
+    return (size_t)(Cin / 128) * Cout * ROWB;
+}
+
+static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who)
+{
+    GDM_CHECK_ARG(w && wpk, "%s: NULL pointer", who);
+    GDM_CHECK_ARG(Cout >= 1 && Cin >= 128 && Cin % 128 == 0, "%s: Cout=%d Cin=%d (Cin %% 128 == 0)", who, Cout, Cin);
+    const long items = (long)taps * (Cin / 128) * Cout * 16;
+    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk);
+    return gdm_launch_status("conv_pack_w_kernel");
+}
+
 extern "C" int gdm_conv3x3_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream)
 {
-    GDM_CHECK_ARG(w && wpk, "gdm_conv3x3_pack_weight_hip: NULL pointer");
-    GDM_CHECK_ARG(Cout >= 1 && Cin >= 128 && Cin % 128 == 0, "gdm_conv3x3_pack_weight_hip: Cout=%d Cin=%d (Cin %% 128 == 0)", Cout, Cin);
-    const long items = 9L * (Cin / 128) * Cout * 16;
-    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, (unsigned char*)wpk);
-    return gdm_launch_status("conv_pack_w_kernel");
+    return pack_weight(w, Cout, Cin, 9, wpk, stream, "gdm_conv3x3_pack_weight_hip");
+}
+
+extern "C" int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream)
+{
+    return pack_weight(w, Cout, Cin, 1, wpk, stream, "gdm_conv1x1_pack_weight_hip");
 }
 
 // xpk must be zero-filled by the caller (the border rows are never written).
@@ -280,4 +314,31 @@ extern "C" int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const fl
     else { if (res) CV(1, true); else CV(1, false); }
 #undef CV
     return gdm_launch_status("conv3x3_bf16x3_kernel");
+}
+
+// 1x1 convolution / GEMM on the same kernel (one tap): out = act(scale * (W x) + shift), x packed by gdm_conv3x3_pack_act_hip.
+// pixel_major != 0 writes out[B*H*W, Cout] (row per pixel) instead of NCHW.
+extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                                      int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1, "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32", W);
+    GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
+    const long ptot = (long)B * H * W;
+    dim3 grid(gdm_cdiv(ptot, CV_PIX), Cout / CV_CO);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        attr = true;
+    }
+#define C1(A, P) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, false, 1, P>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+    if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }
+    else { if (pixel_major) C1(1, true); else C1(1, false); }
+#undef C1
+    return gdm_launch_status("conv1x1_bf16x3_kernel");
 }

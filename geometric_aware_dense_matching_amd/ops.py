@@ -459,6 +459,39 @@ def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None)
     return out
 
 
+def gemm_supported(cin, cout, npix):
+    return cin % 128 == 0 and cout % 128 == 0 and npix % 32 == 0
+
+
+def gemm_pack_weight(weight2d):
+    """W f32[Cout,Cin] -> packed split-bf16 rows for gemm_bf16x3."""
+    w = _dev(weight2d.detach(), torch.float32, "weight")
+    Cout, Cin = w.shape
+    L = _lib.lib()
+    wpk = torch.empty(L.gdm_conv1x1_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
+    check(L.gdm_conv1x1_pack_weight_hip(w.data_ptr(), Cout, Cin, wpk.data_ptr(), _stream()), "gdm_conv1x1_pack_weight_hip")
+    return wpk
+
+
+def gemm_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, pixel_major=False):
+    """out[b] = act(scale * (W @ x[b]) + shift) on split-bf16 MFMA.  x f32[B,Cin,n] (channel-major, n % 32 == 0) ->
+    f32[B,cout,n], or f32[B*n, cout] when pixel_major.  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, Cin, n = x.shape
+    L = _lib.lib()
+    key = (B, Cin, 1, n, x.device.index, torch.cuda.current_stream().cuda_stream)
+    xpk = _conv_act_cache.get(key)
+    if xpk is None:
+        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(B, Cin, 1, n), dtype=torch.uint8, device=x.device)
+        _conv_act_cache[key] = xpk
+    check(L.gdm_conv3x3_pack_act_hip(x.data_ptr(), B, Cin, 1, n, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
+    out = torch.empty((B * n, cout) if pixel_major else (B, cout, n), dtype=torch.float32, device=x.device)
+    check(L.gdm_conv1x1_packed_hip(xpk.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                   shift.data_ptr() if shift is not None else None, B, Cin, cout, 1, n, act,
+                                   1 if pixel_major else 0, out.data_ptr(), _stream()), "gdm_conv1x1_packed_hip")
+    return out
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

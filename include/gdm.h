@@ -250,6 +250,14 @@ int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias
  * x f32[planes,H,W] -> o1 f32[planes,1], o2 [planes,4], o3 [planes,9], o6 [planes,36] (PyTorch bin edges). */
 int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, float* o2, float* o3, float* o6, void* stream);
 
+/* 1x1 convolution / GEMM on the same split-bf16 MFMA kernel (one tap): x packed by gdm_conv3x3_pack_act_hip, weights
+ * f32[Cout,Cin] packed by gdm_conv1x1_pack_weight_hip.  out = act(scale*(W x)+shift) as f32[B,Cout,H,W], or, with
+ * pixel_major != 0, as f32[B*H*W, Cout] (used for the dense part of SplineConv: nodes x (125*128)). */
+size_t gdm_conv1x1_weight_bytes(int Cout, int Cin);
+int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream);
+int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                           int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

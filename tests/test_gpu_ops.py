@@ -355,3 +355,17 @@ def test_final_stage_and_psp_pools(ops):
     f2 = torch.from_numpy(rs.randn(1, 3, 13, 9).astype(np.float32))                 # uneven bins
     for s_, o in zip((1, 2, 3, 6), ops.psp_pools(f2.cuda())):
         assert torch.allclose(o.cpu(), torch.nn.functional.adaptive_avg_pool2d(f2, s_), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,n", [(2, 128, 256, 1024), (1, 1024, 2304, 1024), (1, 128, 16000, 8192)])
+def test_gemm_bf16x3(ops, B, Cin, Cout, n):
+    rs = np.random.RandomState(Cin + n)
+    x = torch.from_numpy(rs.randn(B, Cin, n).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin) / np.sqrt(Cin)).astype(np.float32))
+    ref = torch.matmul(w.double(), x.double())
+    wpk = ops.gemm_pack_weight(w.cuda())
+    got = ops.gemm_bf16x3(x.cuda(), wpk, Cout).cpu()
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got.double() - ref).abs().max().item() < tol
+    got_pm = ops.gemm_bf16x3(x.cuda(), wpk, Cout, pixel_major=True).cpu().view(B, n, Cout).transpose(1, 2)
+    assert (got_pm.double() - ref).abs().max().item() < tol

@@ -19,3 +19,11 @@ for Cin, Cout in ((128, 256), (256, 256), (256, 512), (512, 512)):
     t_us = tm(lambda: ops.conv3x3_bf16x3(x, wpk, Cout))
     gf = 2.0 * B * 1024 * Cin * Cout * 9 / 1e9
     print("%4d->%4d: MIOpen %7.1f us (%6.1f TF/s)   bf16x3 %7.1f us (%6.1f TF/s fp32-equivalent)" % (Cin, Cout, t_mi, gf / t_mi * 1e-3 * 1e3 / 1e3 * 1e3, t_us, gf / t_us))
+print("--- 1x1 / GEMM ---")
+for Cin, Cout, n, Bb in ((1024, 2304, 1024, 16), (512, 1024, 1024, 16), (1024, 1024, 1024, 16), (512, 512, 1024, 16), (128, 16000, 8192, 1)):
+    x = torch.randn(Bb, Cin, n, device="cuda"); w = torch.randn(Cout, Cin, device="cuda") / Cin ** 0.5
+    wpk = ops.gemm_pack_weight(w)
+    t_mi = tm(lambda: torch.matmul(w, x))
+    t_us = tm(lambda: ops.gemm_bf16x3(x, wpk, Cout))
+    gf = 2.0 * Bb * n * Cin * Cout / 1e9
+    print("%4d->%5d n=%5d B=%2d: hipBLASLt %7.1f us   bf16x3 %7.1f us (%6.1f TF/s fp32-equivalent)" % (Cin, Cout, n, Bb, t_mi, t_us, gf / t_us * 1e3 / 1e3))
