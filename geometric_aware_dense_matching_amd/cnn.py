@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import act_code, folded_bn, fused_eval
+from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval
 
 
 # GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
@@ -154,7 +154,11 @@ class PSPModule(nn.Module):
             # no full-resolution priors
             ms, wf = self._split_weights()
             B, Cin = feats.shape[0], feats.shape[1]
-            g = torch.matmul(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
+            if USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
+                wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
+                g = ops.gemm_bf16x3(feats.reshape(B, Cin, h * w), wpk, co).view(B, -1, h, w)
+            else:
+                g = torch.matmul(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
             sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
             pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and 36 <= h * w <= 4096 and h >= 6 and w >= 6 else None
             ys = []
@@ -200,7 +204,11 @@ class PSPUpsample(nn.Module):
                 # conv3x3(up(x)) = 9-tap bilinear gather of a LOW-resolution 1x1 convolution (4x fewer FLOPs, no
                 # 2x-resolution intermediate), BN (with the conv bias) + PReLU folded into the gather's epilogue
                 Bx, Cin, Hx, Wx = x.shape
-                z = torch.matmul(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
+                if USE_MFMA_GEMM and ops.gemm_supported(Cin, 9 * conv.out_channels, Hx * Wx):
+                    wpk, c9 = cached_gemm_weight(self, "tap", self._tap_major_weight, (conv.weight,))
+                    z = ops.gemm_bf16x3(x.reshape(Bx, Cin, Hx * Wx), wpk, c9).view(Bx, -1, Hx, Wx)      # split-bf16 MFMA
+                else:
+                    z = torch.matmul(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
                 scale, shift = folded_bn(self.conv[2], conv.bias)
                 return ops.upconv3x3_gather(z, scale, shift, conv.out_channels, (x.shape[2] * 2, x.shape[3] * 2), code[0], code[1])
         return self.conv(x)

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .cnn import PSPNet
-from .layers import act_code, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
+from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
 from .randla import DilatedResBlock
 
 
@@ -120,7 +120,11 @@ class FFB6DEmb(nn.Module):
             if code is not None:
                 wa, wb = self._split_fuse_weight(fuse_layer, c)
                 t = torch.matmul(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
-                x = torch.matmul(wa, rgb_emb0.reshape(bs, c, hr * wr))                        # [B,Cout,HW]
+                if USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
+                    wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
+                    x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA
+                else:
+                    x = torch.matmul(wa, rgb_emb0.reshape(bs, c, hr * wr))                    # [B,Cout,HW]
                 scale, shift = folded_bn(fuse_layer.normlayer.bn)
                 y = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1])
                 return y.view(bs, -1, hr, wr)

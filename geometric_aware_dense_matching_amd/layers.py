@@ -36,6 +36,23 @@ def folded_bn(bn, conv_bias=None):
     return cache[1], cache[2]
 
 
+def cached_gemm_weight(owner, tag, weight2d, deps):
+    """Packed split-bf16 GEMM weight of `weight2d` (a [Cout,Cin] tensor, or a callable producing it), cached on `owner`
+    under `tag` until any tensor in `deps` changes."""
+    key = tuple((t._version, t.data_ptr()) for t in deps)
+    slot = "_gdm_gemm_" + tag
+    cache = owner.__dict__.get(slot)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w = weight2d() if callable(weight2d) else weight2d
+            cache = (key, ops.gemm_pack_weight(w.contiguous()), w.shape[0])
+        owner.__dict__[slot] = cache
+    return cache[1], cache[2]
+
+
+USE_MFMA_GEMM = __import__("os").environ.get("GDM_MFMA_GEMM", "1") != "0"
+
+
 def act_code(act):
     """(ops.ACT_*, slope) of an activation module; None when it is not one the fused kernel knows."""
     if act is None:

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from ._lib import check
+from .layers import USE_MFMA_GEMM, cached_gemm_weight
 from .synthetic import COLOR_MEAN, COLOR_STD_MESH
 
 KERNEL_SIZE = 5
@@ -79,6 +80,15 @@ class SplineConv(nn.Module):
 
     def forward(self, x, rowptr, src, attr, relu=False):
         M = x.shape[0]
+        nk = KERNEL_SIZE ** 3
+        if (USE_MFMA_GEMM and not torch.is_grad_enabled() and x.is_cuda
+                and ops.gemm_supported(self.cin, nk * self.cout, M)):
+            # dense part on the split-bf16 MFMA GEMM, written node-major ([M, 125*out]) as the aggregation kernel reads it
+            wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin),
+                                        (self.weight,))
+            xw = ops.gemm_bf16x3(x.t().contiguous().unsqueeze(0), wpk, nk * self.cout, pixel_major=True).view(M, nk, self.cout)
+            root = self.lin(x)
+            return _SplineAggregate.apply(xw, root, self.bias, rowptr, src, attr, relu)
         w = self.weight.permute(1, 0, 2).reshape(self.cin, -1)            # [in, 125*out]
         xw = torch.matmul(x, w).view(M, KERNEL_SIZE ** 3, self.cout)      # dense GEMM
         root = self.lin(x)
