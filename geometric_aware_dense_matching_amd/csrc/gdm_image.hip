@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float*
 // floats per pixel); a thread owns one pixel, keeps the C output channels in registers, weights arrive as wave-uniform
 // scalar loads, log-softmax stays in-thread.  Exact fp32 FMAs.
 template <int C>
-__global__ __launch_bounds__(256) void conv1x1_logsoftmax_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv1x1_logsoftmax_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                  const float* __restrict__ bias, long hw, float* __restrict__ out)
 {
     const int b = blockIdx.y;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void conv1x1_logsoftmax_kernel(const float* __
     for (int ci = 0; ci < C; ++ci) {
         const float xv = xb[(long)ci * hw];
 #pragma unroll
-        for (int co = 0; co < C; ++co) y[co] = fmaf(w[co * C + ci], xv, y[co]);
+        for (int co = 0; co < C; ++co) y[co] = fmaf(wt[ci * C + co], xv, y[co]);   // wt = W^T: 64 contiguous scalars per ci
     }
     float m = y[0];
 #pragma unroll
@@ -386,22 +386,31 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
     const float* xp = x + plane * hw;
     for (int i = threadIdx.x; i < hw; i += 256) tile[i] = xp[i];
     __syncthreads();
-    // 1 + 4 + 9 + 36 = 50 bins; one thread per bin
+    // 1 + 4 + 9 + 36 = 50 bins; lanes per bin in proportion to its area: 64 | 4x16 | 9x4 | 36x1 = 200 threads,
+    // each group a power-of-two run of consecutive lanes so a shuffle reduction finishes the bin
     const int t = threadIdx.x;
-    int s, bi;
+    int s, bi, gsz, gl;
     float* o;
-    if (t < 1) { s = 1; bi = t; o = o1 + plane; }
-    else if (t < 5) { s = 2; bi = t - 1; o = o2 + plane * 4; }
-    else if (t < 14) { s = 3; bi = t - 5; o = o3 + plane * 9; }
-    else if (t < 50) { s = 6; bi = t - 14; o = o6 + plane * 36; }
-    else return;
+    if (t < 64) { s = 1; bi = 0; gsz = 64; gl = t; o = o1 + plane; }
+    else if (t < 128) { s = 2; bi = (t - 64) >> 4; gsz = 16; gl = (t - 64) & 15; o = o2 + plane * 4; }
+    else if (t < 164) { s = 3; bi = (t - 128) >> 2; gsz = 4; gl = (t - 128) & 3; o = o3 + plane * 9; }
+    else if (t < 200) { s = 6; bi = t - 164; gsz = 1; gl = 0; o = o6 + plane * 36; }
+    else { s = 1; bi = 0; gsz = 1; gl = 0; o = nullptr; }
     const int by = bi / s, bx = bi - by * s;
     const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
     const int x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
+    const int bw = x1 - x0, cnt = (y1 - y0) * bw;
     float acc = 0.f;
-    for (int yy = y0; yy < y1; ++yy)
-        for (int xx = x0; xx < x1; ++xx) acc += tile[yy * W + xx];
-    o[bi] = acc / (float)((y1 - y0) * (x1 - x0));
+    if (o)
+        for (int i = gl; i < cnt; i += gsz) {
+            const int yy = y0 + i / bw, xx = x0 + i - (i / bw) * bw;
+            acc += tile[yy * W + xx];
+        }
+    for (int m = 1; m < 64; m <<= 1) {
+        const float other = __shfl_xor(acc, m, 64);
+        if (m < gsz) acc += other;
+    }
+    if (o && gl == 0) o[bi] = acc / (float)cnt;
 }
 
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

@@ -397,11 +397,19 @@ def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     return x
 
 
+_final_wt_cache = {}
+
+
 def conv1x1_logsoftmax(x, weight, bias):
     """log_softmax over channels of a 64->64 1x1 convolution, one pass (the `final` stage, pspnet.py:108-112). Inference only."""
     x = _dev(x, torch.float32, "x")
     B, C, H, W = x.shape
-    w = _dev(weight.detach().reshape(C, C), torch.float32, "weight")
+    key = (weight._version, weight.data_ptr())
+    cache = _final_wt_cache.get(id(weight))
+    if cache is None or cache[0] != key:
+        cache = (key, weight.detach().reshape(C, C).t().contiguous())      # W^T: the kernel reads 64 contiguous scalars per ci
+        _final_wt_cache[id(weight)] = cache
+    w = cache[1]
     out = torch.empty_like(x)
     check(_lib.lib().gdm_conv1x1_logsoftmax_hip(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                 B, C, H * W, out.data_ptr(), _stream()), "gdm_conv1x1_logsoftmax_hip")
