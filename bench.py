@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (default). gloo only to rehearse the multi-process path on a 1-GPU box "
                          "(all ranks then share cuda:0 via GDM_FORCE_DEVICE=0)")
+    ap.add_argument("--exact-f32", action="store_true",
+                    help="strict fp32 products everywhere: f32-MFMA matching, trunk convolutions / GEMMs on MIOpen / hipBLASLt "
+                         "(default: split-bf16 MFMA, hi*hi+hi*lo+lo*hi with fp32 accumulation, |err| <= 3*2^-18 per product)")
     ap.add_argument("--cpu-crops", type=int, default=96, help="crops in the bounded CPU sample (~10-20 s of host work)")
     return ap.parse_args()
 
@@ -95,6 +98,10 @@ def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
 
 def main():
     args = parse()
+    if args.exact_f32:                      # read by the package at import time
+        os.environ["GDM_MFMA_CONV"] = "0"
+        os.environ["GDM_MFMA_GEMM"] = "0"
+        args.precision = "f32"
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -248,7 +255,10 @@ def main():
             "config": {"workload": "LineMOD obj_01 batch=%d/GPU, N=%d scene pts x M=%d model kps, crop 256x256, geoMatch "
                                    "(CNN+RandLA+SplineCNN) fwd-only + kNN pyramid + matching" % (B, N, M),
                        "batch_per_gpu": B, "global_batch": B * world, "n_points": N, "n_model": M,
-                       "match_precision": args.precision, "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
+                       "match_precision": args.precision,
+                       "product_arithmetic": "exact f32" if args.exact_f32 else "split-bf16 MFMA x3 (fp32 accumulate) for matching, 32x32-res "
+                                             "3x3 convs and large 1x1 mixes; f32 elsewhere",
+                       "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
             "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
                          "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
             "roofline": roofline, "roofline_fused": roofline_fused, "cpu_baseline": cpu,
