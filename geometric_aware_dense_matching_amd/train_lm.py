@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import matching, pyramid, synthetic
+from . import matching, pose, pyramid, synthetic
 from .checkpoint import load_checkpoint, save_checkpoint
 from .config import LM_DIAMETERS, make_model_cfg
 from .geoMatch import GeoMatch
@@ -235,9 +235,10 @@ def test(args):
             t0 = time.perf_counter()
             ep, cu = model_fn_dec(model, batch, device)
             res = matching.match_frames(ep)
+            RT, valid = pose.solve_poses(res, cu["cld_rgb_nrm"], model.model_emb.xyz)        # evaluator.py:94-100, batched on the GPU
             torch.cuda.synchronize()
             results.append(dict(time=time.perf_counter() - t0, count=res["count"].cpu(), best_idx=res["best_idx"].cpu(),
-                                best_sim=res["best_sim"].cpu(), mask=res["mask"].cpu()))
+                                best_sim=res["best_sim"].cpu(), mask=res["mask"].cpu(), RT=RT.cpu(), valid=valid.cpu()))
     return results
 
 

@@ -333,3 +333,32 @@ def test_fused_eval_path_equals_module_path(golden_model):
     b = model(dict(d))                                   # grad enabled -> module path
     for k in ("rgbd", "seg"):
         assert torch.allclose(a[k], b[k].detach(), rtol=1e-4, atol=2e-4), k
+
+
+def test_multi_object_driver_equals_per_instance_forwards():
+    """infer.run_multi_object (instances grouped per object, batched) vs the reference's way (one batch-1 forward per
+    instance through that instance's model, train_lm.py:298-314)."""
+    from geometric_aware_dense_matching_amd import infer, matching, pyramid
+    from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+    models = {}
+    for cid in (1, 5):
+        m = GeoMatch(make_model_cfg(n_mesh_node=256), cid, model_points=synthetic.make_model_points(cid, 256, 150.0))
+        sd = synthetic.synthetic_state_dict({k: v for k, v in m.state_dict().items()
+                                             if not k.startswith("model_emb.mesh_graph") and k not in ("model_emb.xyz", "model_emb.const_one")}, seed=cid)
+        m.load_state_dict(sd, strict=False)
+        models[cid] = m.cuda().eval()
+    cls = [5, 1, 5, 1, 1]
+    batch = synthetic.make_batch(seed=55, batch=len(cls), n_points=1024)
+    d = _dev_inputs(batch)
+    got = infer.run_multi_object(models, d, cls)
+    assert got["rgbd"].shape == (5, 128, 1024) and got["mesh"].shape == (5, 128, 256) and got["RT"].shape == (5, 3, 4)
+    for i, cid in enumerate(cls):
+        one = {k: v[i:i + 1] for k, v in d.items()}
+        one.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(one["cld_rgb_nrm"]), one["dpt_xyz"]))
+        with torch.no_grad():
+            ep = models[cid](one)
+            res = matching.match_frames(ep)
+        assert torch.allclose(got["rgbd"][i], ep["rgbd"][0], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(got["seg"][i], ep["seg"][0], rtol=1e-4, atol=1e-4)
+        assert torch.equal(got["mesh"][i], ep["mesh"][0])
+        assert (got["best_idx"][i] == res["best_idx"][0]).float().mean().item() > 0.995
