@@ -71,6 +71,7 @@ SIGNATURES = {
     "gdm_conv1x1_weight_bytes": (_sz, [_i, _i]),
     "gdm_conv1x1_pack_weight_hip": (_i, [_vp, _i, _i, _vp, _vp]),
     "gdm_conv1x1_packed_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_depth_to_xyz_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }

@@ -413,6 +413,27 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
     if (o && gl == 0) o[bi] = acc / (float)cnt;
 }
 
+// depth (metres) -> camera-frame xyz for a crop window of a frame, as dpt_2_pcld + the integer crop of the loader
+// (/root/reference/datasets/lm/linemod_pbr.py:398-411,473): x = (u - cx) d / fx, y = (v - cy) d / fy, z = d, zeros where d <= 1e-8.
+// depth f32[B,H,W]; K f32[B,3,3]; crop origin (x0,y0) i32[B,2]; out f32[B,S,S,3].
+__global__ __launch_bounds__(256) void depth_to_xyz_kernel(const float* __restrict__ depth, const float* __restrict__ K,
+                                                           const int32_t* __restrict__ origin, int H, int W, int S, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * S) return;
+    const int v = origin[2 * b + 1] + i / S, u = origin[2 * b] + i % S;
+    float d = 0.f;
+    if (u >= 0 && u < W && v >= 0 && v < H) d = depth[((long)b * H + v) * W + u];
+    const float* k = K + b * 9;
+    const float fx = k[0], cx = k[2], fy = k[4], cy = k[5];
+    const float m = d > 1e-8f ? 1.f : 0.f;
+    float* o = out + ((long)b * S * S + i) * 3;
+    o[0] = __fmul_rn(__fdiv_rn(__fmul_rn(__fsub_rn((float)u, cx), d), fx), m);
+    o[1] = __fmul_rn(__fdiv_rn(__fmul_rn(__fsub_rn((float)v, cy), d), fy), m);
+    o[2] = __fmul_rn(d, m);
+}
+
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -535,4 +556,13 @@ extern "C" int gdm_psp_pools_hip(const float* x, long planes, int H, int W, floa
     GDM_CHECK_ARG(planes >= 1 && H >= 6 && W >= 6 && H * W <= 64 * 64, "gdm_psp_pools_hip: map %dx%d must be between 6x6 and 64x64 pixels", H, W);
     hipLaunchKernelGGL(psp_pools_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, H, W, o1, o2, o3, o6);
     return gdm_launch_status("psp_pools_kernel");
+}
+
+extern "C" int gdm_depth_to_xyz_hip(const float* depth, const float* K, const int32_t* origin, int B, int H, int W, int S,
+                                    float* out, void* stream)
+{
+    GDM_CHECK_ARG(depth && K && origin && out, "gdm_depth_to_xyz_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && S >= 1, "gdm_depth_to_xyz_hip: bad shape");
+    hipLaunchKernelGGL(depth_to_xyz_kernel, dim3(gdm_cdiv((long)S * S, 256), B), dim3(256), 0, (hipStream_t)stream, depth, K, origin, H, W, S, out);
+    return gdm_launch_status("depth_to_xyz_kernel");
 }

@@ -258,6 +258,11 @@ int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, vo
 int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
                            int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream);
 
+/* Front end: depth (m) f32[B,H,W] + intrinsics K f32[B,3,3] + integer crop origin (x0,y0) i32[B,2] -> camera-frame
+ * xyz f32[B,S,S,3] of the SxS crop (datasets/lm/linemod_pbr.py:398-411 dpt_2_pcld; zeros where depth <= 1e-8). */
+int gdm_depth_to_xyz_hip(const float* depth, const float* K, const int32_t* origin, int B, int H, int W, int S,
+                         float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,3 +362,31 @@ def test_multi_object_driver_equals_per_instance_forwards():
         assert torch.allclose(got["seg"][i], ep["seg"][0], rtol=1e-4, atol=1e-4)
         assert torch.equal(got["mesh"][i], ep["mesh"][0])
         assert (got["best_idx"][i] == res["best_idx"][0]).float().mean().item() > 0.995
+
+
+def test_gpu_front_end_vs_synthetic_generator(golden_model):
+    """frontend.make_inputs (depth -> xyz crop -> sampling -> pyramid on the device) against the host generator's
+    arithmetic (same dpt_2_pcld formula) and the oracle pyramid; then a forward runs on it."""
+    from geometric_aware_dense_matching_amd import frontend
+    from oracle import pyramid as opyr
+    model, _ = golden_model
+    rs = np.random.RandomState(77)
+    depth, rgb, nrm = synthetic.make_frame(rs)
+    S, N = 256, 1024
+    y0, x0 = (480 - S) // 2, (640 - S) // 2
+    want_xyz = synthetic.depth_to_xyz(depth)[y0:y0 + S, x0:x0 + S]
+    dev = torch.device("cuda")
+    rgb_n = torch.from_numpy(synthetic.normalize_color(rgb).transpose(2, 0, 1)[None].copy()).to(dev)
+    inp = frontend.make_inputs(rgb_n, torch.from_numpy(depth[None]).to(dev), torch.from_numpy(nrm.transpose(2, 0, 1)[None].copy()).to(dev),
+                               torch.from_numpy(synthetic.LM_K[None]).to(dev), torch.tensor([[x0, y0]], dtype=torch.int32, device=dev), S, N)
+    assert np.allclose(inp["dpt_xyz"][0].cpu().numpy(), want_xyz, rtol=1e-6, atol=1e-7)
+    ch = inp["choose"][0, 0].cpu().numpy()
+    assert len(np.unique(ch)) == N and (want_xyz.reshape(-1, 3)[ch, 2] > 1e-6).all()           # valid, without replacement
+    cld = inp["cld_rgb_nrm"][0, :3].t().cpu().numpy()
+    assert np.array_equal(cld, inp["dpt_xyz"][0].reshape(-1, 3)[torch.from_numpy(ch).long().cuda()].cpu().numpy())
+    want = opyr.build_pyramid(cld.copy(), inp["dpt_xyz"][0].cpu().numpy())
+    for k, v in want.items():
+        assert np.array_equal(inp[k][0].cpu().numpy(), v), k
+    with torch.no_grad():
+        ep = model(inp)
+    assert torch.isfinite(ep["rgbd"]).all() and ep["rgbd"].shape == (1, 128, N)
