@@ -25,6 +25,8 @@ from . import ops
 from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval
 
 
+# the low-resolution form of conv3x3(upsample(x)) needs a 9*Cout-channel intermediate: it pays when Cin is large
+UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 # GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
 USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
 
@@ -200,7 +202,7 @@ class PSPUpsample(nn.Module):
         if fused_eval(x, self):
             code = act_code(self.conv[3])
             conv = self.conv[1]
-            if code is not None and x.shape[0] * conv.out_channels <= 65535:
+            if code is not None and x.shape[0] * conv.out_channels <= 65535 and conv.in_channels >= UPCONV_MIN_CIN:
                 # conv3x3(up(x)) = 9-tap bilinear gather of a LOW-resolution 1x1 convolution (4x fewer FLOPs, no
                 # 2x-resolution intermediate), BN (with the conv bias) + PReLU folded into the gather's epilogue
                 Bx, Cin, Hx, Wx = x.shape

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
                                                                    const float* __restrict__ shift, int Cout, int H, int W, int OH, int OW,
                                                                    float rh, float rw, float slope, float* __restrict__ out)
 {
-    __shared__ float patch[9][UP_PH][UP_PW + 1];
+    // one extra row and column (clamped duplicates) so that the "+1" bilinear neighbour always exists in the patch: its
+    // weight is 0 whenever it is a duplicate, and the two reads of a row become one ds_read2_b32
+    __shared__ float patch[9][UP_PH + 1][UP_PW + 2];
     const int bc = blockIdx.z;
     const int b = bc / Cout, co = bc - b * Cout;
     const int ox_t = blockIdx.x * UT_W, oy_t = blockIdx.y * UT_H;
@@ -209,30 +211,32 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
     const int ys1 = min((int)(rh * (float)min(oy_t + UT_H, OH - 1)) + 1, H - 1);
     const int xs0 = min((int)(rw * (float)max(ox_t - 1, 0)), W - 1);
     const int xs1 = min((int)(rw * (float)min(ox_t + UT_W, OW - 1)) + 1, W - 1);
-    const int ph = ys1 - ys0 + 1, pw = xs1 - xs0 + 1;           // <= UP_PH, UP_PW (checked on the host)
+    const int ph = ys1 - ys0 + 2, pw = xs1 - xs0 + 2;           // incl. the duplicate row / column
     const long plane_sz = (long)H * W;
     const float* zb = z + ((long)b * 9 * Cout + co) * plane_sz;
-    for (int i = threadIdx.x; i < 9 * ph * pw; i += 256) {
-        const int tap = i / (ph * pw);
-        const int r = (i - tap * ph * pw) / pw;
-        const int c = i - tap * ph * pw - r * pw;
-        patch[tap][r][c] = zb[(long)tap * Cout * plane_sz + (long)(ys0 + r) * W + xs0 + c];
+    // (r, c) = (i / pw, i % pw) by a 20-bit reciprocal (exact for i < 2^12, 3 <= pw <= 38): no integer division in the fill loop
+    const unsigned inv_pw = ((1u << 20) + pw - 1) / pw;
+    for (int i = threadIdx.x; i < ph * pw; i += 256) {
+        const int r = (int)(((unsigned)i * inv_pw) >> 20);
+        const int c = i - r * pw;
+        const float* src = zb + (long)min(ys0 + r, H - 1) * W + min(xs0 + c, W - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) patch[tap][r][c] = src[(long)tap * Cout * plane_sz];
     }
     __syncthreads();
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 quads x 16 rows
     const int oy = oy_t + ty, ox0 = ox_t + tx * 4;
     if (oy >= OH || ox0 >= OW) return;
-    int cx0[6], cx1[6];
+    int cx0[6];
     float clx[6];
     bool cok[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int ox = ox0 - 1 + j;
         cok[j] = ox >= 0 && ox < OW;
-        const float sx = rw * (float)max(ox, 0);
+        const float sx = rw * (float)min(max(ox, 0), OW - 1);
         const int x0 = min((int)sx, W - 1);
         cx0[j] = x0 - xs0;
-        cx1[j] = x0 + (x0 < W - 1 ? 1 : 0) - xs0;
         clx[j] = sx - (float)x0;
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -242,19 +246,19 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
         if (yy < 0 || yy >= OH) continue;
         const float sy = rh * (float)yy;
         const int y0 = min((int)sy, H - 1);
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
         const float ly = sy - (float)y0, hy = 1.f - ly;
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int tap = (dy + 1) * 3 + (dx + 1);
             const float* r0 = &patch[tap][y0 - ys0][0];
-            const float* r1 = &patch[tap][y1 - ys0][0];
+            const float* r1 = r0 + (UP_PW + 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = j + dx + 1;
                 if (cok[c] && ox0 + j < OW) {
                     const float lx = clx[c], hx = 1.f - lx;
-                    acc[j] += hy * (hx * r0[cx0[c]] + lx * r0[cx1[c]]) + ly * (hx * r1[cx0[c]] + lx * r1[cx1[c]]);
+                    const int xo = cx0[c];
+                    acc[j] += hy * (hx * r0[xo] + lx * r0[xo + 1]) + ly * (hx * r1[xo] + lx * r1[xo + 1]);
                 }
             }
         }
