@@ -390,3 +390,26 @@ def test_gpu_front_end_vs_synthetic_generator(golden_model):
     with torch.no_grad():
         ep = model(inp)
     assert torch.isfinite(ep["rgbd"]).all() and ep["rgbd"].shape == (1, 128, N)
+
+
+def test_graphed_pipeline_equals_eager(golden_model):
+    """One hipGraph replay of pyramid + forward + matching + pose == the eager step on new inputs."""
+    from geometric_aware_dense_matching_amd import infer, matching, pose, pyramid
+    model, _ = golden_model
+    b0 = _dev_inputs(synthetic.make_batch(seed=61, batch=2, n_points=1024))
+    b0.pop("labels")
+    gp = infer.GraphedPipeline(model, b0)
+    b1 = _dev_inputs(synthetic.make_batch(seed=62, batch=2, n_points=1024))
+    b1.pop("labels")
+    got = {k: v.clone() for k, v in gp(b1).items()}
+    d = dict(b1)
+    d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"]))
+    with torch.no_grad():
+        ep = model(d)
+        res = matching.match_frames(ep)
+        RT, valid = pose.solve_poses(res, d["cld_rgb_nrm"], model.model_emb.xyz)
+    assert torch.allclose(got["rgbd"], ep["rgbd"], rtol=1e-4, atol=1e-4)
+    assert (got["best_idx"] == res["best_idx"]).float().mean().item() > 0.995
+    assert torch.equal(got["valid"], valid)
+    if bool(valid.all()):
+        assert torch.allclose(got["RT"], RT, atol=1e-3)
