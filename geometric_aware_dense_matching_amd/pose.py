@@ -27,25 +27,15 @@ def kabsch_stats(res, cld_rgb_nrm, model_xyz):
 
 
 def solve_poses(res, cld_rgb_nrm, model_xyz, min_points=5):
-    """-> RT f32[B,3,4] mapping model coordinates to the camera frame, valid bool[B]."""
+    """-> RT f32[B,3,4] mapping model coordinates to the camera frame, valid bool[B].  Two launches (statistics, fit), no
+    host synchronisation."""
     st = kabsch_stats(res, cld_rgb_nrm, model_xyz)
-    n = st[:, 0]
-    valid = n >= min_points
-    nn = n.clamp(min=1.0)
-    cA, cB = st[:, 1:4] / nn[:, None], st[:, 4:7] / nn[:, None]
-    H = st[:, 7:16].view(-1, 3, 3) - nn[:, None, None] * cA[:, :, None] * cB[:, None, :]      # AA^T BB
-    H = torch.where(valid[:, None, None], H, torch.eye(3, dtype=H.dtype, device=H.device).expand_as(H))
-    U, S, Vt = torch.linalg.svd(H)
-    R = Vt.transpose(1, 2) @ U.transpose(1, 2)
-    neg = torch.linalg.det(R) < 0                               # reflection case: flip the last row of Vt
-    Vt = torch.where(neg[:, None, None] & (torch.arange(3, device=H.device) == 2)[None, :, None], -Vt, Vt)
-    R = Vt.transpose(1, 2) @ U.transpose(1, 2)
-    t = cB - (R @ cA[:, :, None]).squeeze(2)
-    RT = torch.cat([R, t[:, :, None]], dim=2)
-    sentinel = torch.eye(4, dtype=RT.dtype, device=RT.device)[:3].clone()
-    sentinel[2, 3] = -1000.0
-    RT = torch.where(valid[:, None, None], RT, sentinel.expand_as(RT))
-    return RT.to(torch.float32), valid
+    B = st.shape[0]
+    RT = torch.empty((B, 3, 4), dtype=torch.float32, device=st.device)
+    valid = torch.empty((B,), dtype=torch.uint8, device=st.device)
+    check(_lib.lib().gdm_kabsch_solve_hip(st.data_ptr(), B, int(min_points), RT.data_ptr(), valid.data_ptr(), ops._stream()),
+          "gdm_kabsch_solve_hip")
+    return RT, valid.bool()
 
 
 def transform(pts, RT):

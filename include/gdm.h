@@ -204,6 +204,12 @@ int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* matc
 int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stride, int ch_stride, const float* model_xyz,
                          const int32_t* best_idx, const uint8_t* mask, int B, int N, int M, double* out, void* stream);
 
+/* The fit itself (pvn3d_eval_utils_kpls.py:55-77: centroids, SVD of H, reflection fix, t = cB - R cA) from those statistics,
+ * on the device: RT f32[B,3,4] maps model coordinates (A) to the camera frame (B); valid u8[B] = n >= min_points, else the
+ * reference's sentinel pose [I | (0,0,-1000)] (evaluator.py:94-96).  The optimal proper rotation is obtained as Horn's unit
+ * quaternion (largest eigenvector of a symmetric 4x4, cyclic Jacobi, f64) -- the same R as SVD + reflection fix. */
+int gdm_kabsch_solve_hip(const double* stats, int B, int min_points, float* RT, uint8_t* valid, void* stream);
+
 /* Inference-mode BatchNorm + activation (+ residual branch with its own folded BatchNorm) in one pass:
  * y = act(x*scale[c] + shift[c] (+ res*res_scale[c] + res_shift[c])), c = plane % C; x,res,y f32[planes, inner],
  * inner % 4 == 0; res / res_scale / res_shift may be NULL (res_scale NULL = plain residual add).
