@@ -494,6 +494,442 @@ __global__ __launch_bounds__(V2_THREADS) void match_panel_kernel(const unsigned 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// match v3: v2's LDS-resident panel, software-pipelined inside the wave (BF16X3, full tiles only)
+// ------------------------------------------------------------------------------------------
+// PMC on v2 (profiles/r01_match_pmc.md): the MFMA pipe is busy 65 % (fused) / 39 % (materialised) of the SIMD's cycles; the two
+// waves of a SIMD fall into phase (both issue MFMAs, then both run their ~130-instruction arg-max/store epilogue), so the pipe
+// idles during every epilogue.  v3 removes the dependence on the partner wave:
+//   * a wave's step t issues the 48 MFMAs of 64-column block t into one accumulator pair WHILE it drains block t-1 from the
+//     other pair (running arg-max, stores), with the fragment reads of the next k-step (and of the next block's first k-step)
+//     in flight; sched_group_barrier pins the interleave MFMA : ds_read : VALU : store, one scheduling region per step;
+//   * the MFMA operand roles are swapped (srcA = model columns from the LDS panel, srcB = scene rows from registers), so a
+//     lane holds 16 columns of ONE scene row per accumulator: the running (max, arg) is a single register pair per lane, the
+//     row-block reduction is one shuffle, and the tile goes out as dwordx4 stores (4 consecutive columns per lane; plain
+//     stores, merged to full lines in L2 -- tools/micro/store_pattern.hip: 5.95 TB/s for this pattern, non-temporal 1.8);
+//   * the next row block's scene operand is prefetched into a second register set at the start of the row block, i.e. ahead of
+//     that row block's stores in vmcnt order (loads issued behind ~100 stores wait for all of them).
+// Requires R % 256 == 0 and M % 256 == 0 (no per-lane predication, so every step is one basic block); other shapes run v2.
+// Same products, same accumulation order as v2: bit-identical results.
+struct BFrag { u32x4 h0, l0, h1, l1; };
+
+__device__ __forceinline__ BFrag read_bfrag(const unsigned char* smem, int c0, int s, int h)
+{
+    BFrag f;
+    f.h0 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 2 * s + h));
+    f.l0 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0, 16 + 2 * s + h));
+    f.h1 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0 + 32, 2 * s + h));
+    f.l1 = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c0 + 32, 16 + 2 * s + h));
+    return f;
+}
+
+// (max, first arg-max) of the 32 values a lane holds for its row in one 64-column block, as a tournament: codes are
+// compile-time constants at the leaves, every node takes its right child only if strictly greater (lower column wins ties).
+// code = 16*acc + reg; column within the block = (reg&3) + 8*(reg>>2) + 32*acc (+ 4*h), ascending in code for a fixed lane.
+__device__ __forceinline__ void block_argmax(const f32x16& p0, const f32x16& p1, float& bm, int& bc)
+{
+    // four independent scan chains over ascending code ranges (8 values each), merged left to right
+    float m[4];
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x16& p = (j < 2) ? p0 : p1;
+        const int r0 = (j & 1) * 8;
+        m[j] = p[r0];
+        c[j] = j * 8;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            const float v = p[r0 + i];
+            const bool t = v > m[j];
+            m[j] = t ? v : m[j];
+            c[j] = t ? j * 8 + i : c[j];
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const bool t = m[j] > m[0];
+        m[0] = t ? m[j] : m[0];
+        c[0] = t ? c[j] : c[0];
+    }
+    bm = m[0];
+    bc = c[0];
+}
+
+// One pipeline step: MFMAs of column block CP into (n0, n1) | drain (p0, p1) = column block PCP of row `prow`.
+//   fr        in: fragments of (CP, k-step 0); out: fragments of ((CP+1)%4, k-step 0)
+//   PREFETCH  : after k-step s, reload areg[s], areg[8+s] with the NEXT row block's operand (their last use in this row block)
+//   DRAIN     : false only for the very first step of a workgroup (nothing to drain yet)
+// acc[reg] of lane (lr, h) = sim[row lr][column (reg&3) + 8*(reg>>2) + 4*h of the 32-column block]
+template <int CP, int PCP, bool PREFETCH, bool DRAIN>
+__device__ __forceinline__ void pipe_step(const unsigned char* smem, int lr, int h, u32x4 (&areg)[16],
+                                          BFrag& fr, f32x16& n0, f32x16& n1, const f32x16& p0, const f32x16& p1,
+                                          float& best, int& bcode, const unsigned char* __restrict__ arow_next)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        n0[i] = 0.f;
+        n1[i] = 0.f;
+    }
+    const int c0 = CP * 64 + lr;
+    const int c0n = ((CP + 1) & 3) * 64 + lr;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const BFrag nx = (s < 7) ? read_bfrag(smem, c0, s + 1, h) : read_bfrag(smem, c0n, 0, h);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[s]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, areg[8 + s]);
+        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, fr.h0), bl0 = __builtin_bit_cast(bf16x8, fr.l0);
+        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, fr.h1), bl1 = __builtin_bit_cast(bf16x8, fr.l1);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl0, ah, n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl1, ah, n1, 0, 0, 0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al, n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, al, n1, 0, 0, 0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah, n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah, n1, 0, 0, 0);
+        if (PREFETCH) {
+            areg[s] = *reinterpret_cast<const u32x4*>(arow_next + (2 * s + h) * 16);
+            areg[8 + s] = *reinterpret_cast<const u32x4*>(arow_next + (16 + 2 * s + h) * 16);
+        }
+        fr = nx;
+    }
+    if (DRAIN) {
+        float lbest;
+        int lcode;
+        block_argmax(p0, p1, lbest, lcode);
+        const bool take = lbest > best;                    // earlier blocks hold lower columns: strict '>' keeps the first maximum
+        best = take ? lbest : best;
+        bcode = take ? lcode + PCP * 32 : bcode;
+    }
+    // interleave: every MFMA is followed by a fragment read and a slice of the epilogue (one pipeline = one sync id per step)
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, CP);
+        if (i < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, CP);
+        if (PREFETCH && (i % 6) == 5) __builtin_amdgcn_sched_group_barrier(0x020, 2, CP);
+        if (DRAIN) __builtin_amdgcn_sched_group_barrier(0x002, 2, CP);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // one scheduling region per step: the interleave pipeline is matched per region
+}
+
+__global__ __launch_bounds__(V2_THREADS) void match_pipe_kernel(const unsigned char* __restrict__ apk,
+                                                                 const unsigned char* __restrict__ bpk,
+                                                                 int R, int M, int G,
+                                                                 float* __restrict__ sim,
+                                                                 float* __restrict__ pval,      // [panels, R]
+                                                                 int32_t* __restrict__ pidx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // PANEL_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31;
+    const int h = lane >> 5;
+    const int g = blockIdx.x % G;
+    const int panel = blockIdx.x / G;
+    const int col0 = panel * PANEL_COLS;
+
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int gi = i * V2_THREADS + tid;
+        const int col = gi >> 5, ch = gi & 31;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(bpk + (long)(col0 + col) * ROW_BYTES + ch * 16);
+        *reinterpret_cast<u32x4*>(smem + lds_chunk_off(col, ch)) = v;
+    }
+    __syncthreads();
+
+    const int nrb = R / V2_ROWS;
+    if (g >= nrb) return;
+    u32x4 areg[16];
+    {
+        const unsigned char* arow = apk + (long)(g * V2_ROWS + wave * 32 + lr) * ROW_BYTES;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            areg[s] = *reinterpret_cast<const u32x4*>(arow + (2 * s + h) * 16);
+            areg[8 + s] = *reinterpret_cast<const u32x4*>(arow + (16 + 2 * s + h) * 16);
+        }
+    }
+    float best = -INFINITY;
+    int bcode = 0;
+    f32x16 a0, a1, b0, b1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        b0[i] = 0.f;
+        b1[i] = 0.f;
+    }
+    BFrag fr = read_bfrag(smem, lr, 0, h);
+
+    // step 0 of the first row block: nothing to drain
+    pipe_step<0, 0, false, false>(smem, lr, h, areg, fr, a0, a1, b0, b1, best, bcode, apk);
+
+    for (int rb = g; rb < nrb; rb += G) {
+        const int row0 = rb * V2_ROWS + wave * 32;                        // uniform
+        const bool has_next = rb + G < nrb;
+        const int nrow = (has_next ? (rb + G) * V2_ROWS : rb * V2_ROWS) + wave * 32 + lr;
+        const unsigned char* arow_next = apk + (long)nrow * ROW_BYTES;
+        pipe_step<1, 0, false, true>(smem, lr, h, areg, fr, b0, b1, a0, a1, best, bcode, arow_next);
+        pipe_step<2, 1, false, true>(smem, lr, h, areg, fr, a0, a1, b0, b1, best, bcode, arow_next);
+        pipe_step<3, 2, true, true>(smem, lr, h, areg, fr, b0, b1, a0, a1, best, bcode, arow_next);
+        if (has_next) {
+            pipe_step<0, 3, false, true>(smem, lr, h, areg, fr, a0, a1, b0, b1, best, bcode, arow_next);
+        } else {
+            float lbest;
+            int lcode;
+            block_argmax(b0, b1, lbest, lcode);
+            const bool take = lbest > best;
+            best = take ? lbest : best;
+            bcode = take ? lcode + 96 : bcode;
+        }
+        // row-block result: code -> column, merge the two half-waves (lower column wins ties), one lane per row writes
+        {
+            int ix = col0 + ((bcode & 3) | (((bcode >> 2) & 3) << 3) | ((bcode >> 4) << 5)) + 4 * h;
+            float v = best;
+            const float ov = __shfl_xor(v, 32, 64);
+            const int oi = __shfl_xor(ix, 32, 64);
+            if (ov > v || (ov == v && oi < ix)) {
+                v = ov;
+                ix = oi;
+            }
+            if (h == 0) {
+                pval[(long)panel * R + row0 + lr] = v;
+                pidx[(long)panel * R + row0 + lr] = ix;
+            }
+        }
+        best = -INFINITY;
+        bcode = 0;
+    }
+}
+
+__device__ __forceinline__ void finalize_rows(const float (&best)[16], const int (&bidx)[16], int lane, int h, int row0, int R,
+                                              int panel, float* __restrict__ pval, int32_t* __restrict__ pidx)
+{
+    // (max, lowest arg) across the 32 lanes of each half-wave, halving the row set every step (as v2)
+    float v8[8];  int i8[8];
+    {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sv = up ? best[i] : best[i + 8];
+            const int si = up ? bidx[i] : bidx[i + 8];
+            const float ov = __shfl_xor(sv, 1, 64);
+            const int oi = __shfl_xor(si, 1, 64);
+            const float mv = up ? best[i + 8] : best[i];
+            const int mi = up ? bidx[i + 8] : bidx[i];
+            const bool take = ov > mv || (ov == mv && oi < mi);
+            v8[i] = take ? ov : mv;
+            i8[i] = take ? oi : mi;
+        }
+    }
+    float v4[4];  int i4[4];
+    {
+        const bool up = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sv = up ? v8[i] : v8[i + 4];
+            const int si = up ? i8[i] : i8[i + 4];
+            const float ov = __shfl_xor(sv, 2, 64);
+            const int oi = __shfl_xor(si, 2, 64);
+            const float mv = up ? v8[i + 4] : v8[i];
+            const int mi = up ? i8[i + 4] : i8[i];
+            const bool take = ov > mv || (ov == mv && oi < mi);
+            v4[i] = take ? ov : mv;
+            i4[i] = take ? oi : mi;
+        }
+    }
+    float v2[2];  int i2[2];
+    {
+        const bool up = lane & 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float sv = up ? v4[i] : v4[i + 2];
+            const int si = up ? i4[i] : i4[i + 2];
+            const float ov = __shfl_xor(sv, 4, 64);
+            const int oi = __shfl_xor(si, 4, 64);
+            const float mv = up ? v4[i + 2] : v4[i];
+            const int mi = up ? i4[i + 2] : i4[i];
+            const bool take = ov > mv || (ov == mv && oi < mi);
+            v2[i] = take ? ov : mv;
+            i2[i] = take ? oi : mi;
+        }
+    }
+    float v1;  int i1;
+    {
+        const bool up = lane & 8;
+        const float sv = up ? v2[0] : v2[1];
+        const int si = up ? i2[0] : i2[1];
+        const float ov = __shfl_xor(sv, 8, 64);
+        const int oi = __shfl_xor(si, 8, 64);
+        const float mv = up ? v2[1] : v2[0];
+        const int mi = up ? i2[1] : i2[0];
+        const bool take = ov > mv || (ov == mv && oi < mi);
+        v1 = take ? ov : mv;
+        i1 = take ? oi : mi;
+    }
+    {
+        const float ov = __shfl_xor(v1, 16, 64);
+        const int oi = __shfl_xor(i1, 16, 64);
+        if (ov > v1 || (ov == v1 && oi < i1)) {
+            v1 = ov;
+            i1 = oi;
+        }
+    }
+    if ((lane & 16) == 0) {
+        const int reg = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+        const int grow = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        pval[(long)panel * R + grow] = v1;
+        pidx[(long)panel * R + grow] = i1;
+    }
+}
+
+// Materialised form of v3: original operand roles (lane = column, register = row), so one dword store instruction covers
+// 2 rows x 128 contiguous bytes and may stay non-temporal; the swapped layout's 16-byte pieces need write-back merging in L2
+// and lose under load (347 vs 256 us).  Running (max, arg) per register, v2's butterfly per row block.
+// Steps of 32 columns (one accumulator in flight, one draining): 24 MFMAs | 16 values drained per step.
+struct BFrag1 { u32x4 h, l; };
+
+__device__ __forceinline__ BFrag1 read_bfrag1(const unsigned char* smem, int c, int s, int h)
+{
+    BFrag1 f;
+    f.h = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c, 2 * s + h));
+    f.l = *reinterpret_cast<const u32x4*>(smem + lds_chunk_off(c, 16 + 2 * s + h));
+    return f;
+}
+
+template <int CP, int PCP, bool RELOAD, bool DRAIN>
+__device__ __forceinline__ void pipe_step_sim(const unsigned char* smem, int lr, int h, u32x4 (&areg)[16], BFrag1& fr,
+                                              f32x16& n, const f32x16& p, float (&best)[16], int (&bidx)[16], int pgc,
+                                              float* __restrict__ pbase, unsigned pvoff, long M,
+                                              const unsigned char* __restrict__ arow_next)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) n[i] = 0.f;
+    const int c = CP * 32 + lr;
+    const int cn = ((CP + 1) & 7) * 32 + lr;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const BFrag1 nx = (s < 7) ? read_bfrag1(smem, c, s + 1, h) : read_bfrag1(smem, cn, 0, h);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[s]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, areg[8 + s]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, fr.h), bl = __builtin_bit_cast(bf16x8, fr.l);
+        n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, n, 0, 0, 0);
+        if (RELOAD) {
+            areg[s] = *reinterpret_cast<const u32x4*>(arow_next + (2 * s + h) * 16);
+            areg[8 + s] = *reinterpret_cast<const u32x4*>(arow_next + (16 + 2 * s + h) * 16);
+        }
+        fr = nx;
+    }
+    if (DRAIN) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float v = p[reg];
+            const bool t = v > best[reg];
+            best[reg] = t ? v : best[reg];
+            bidx[reg] = t ? pgc : bidx[reg];
+            float* o = pbase + (long)((reg & 3) + 8 * (reg >> 2)) * M + PCP * 32;     // uniform row base, per-lane 32-bit offset
+            __builtin_nontemporal_store(v, o + pvoff);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, CP);
+        if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, CP);
+        if (DRAIN) __builtin_amdgcn_sched_group_barrier(0x002, 2, CP);
+        if (DRAIN && i >= 4 && i < 20) __builtin_amdgcn_sched_group_barrier(0x040, 1, CP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(V2_THREADS) void match_pipe_sim_kernel(const unsigned char* __restrict__ apk,
+                                                                     const unsigned char* __restrict__ bpk,
+                                                                     int R, int M, int G,
+                                                                     float* __restrict__ sim,
+                                                                     float* __restrict__ pval,      // [panels, R]
+                                                                     int32_t* __restrict__ pidx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // PANEL_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31;
+    const int h = lane >> 5;
+    const int g = blockIdx.x % G;
+    const int panel = blockIdx.x / G;
+    const int col0 = panel * PANEL_COLS;
+
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int gi = i * V2_THREADS + tid;
+        const int col = gi >> 5, ch = gi & 31;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(bpk + (long)(col0 + col) * ROW_BYTES + ch * 16);
+        *reinterpret_cast<u32x4*>(smem + lds_chunk_off(col, ch)) = v;
+    }
+    __syncthreads();
+
+    const int nrb = R / V2_ROWS;
+    if (g >= nrb) return;
+    u32x4 areg[16];
+    {
+        const unsigned char* arow = apk + (long)(g * V2_ROWS + wave * 32 + lr) * ROW_BYTES;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            areg[s] = *reinterpret_cast<const u32x4*>(arow + (2 * s + h) * 16);
+            areg[8 + s] = *reinterpret_cast<const u32x4*>(arow + (16 + 2 * s + h) * 16);
+        }
+    }
+    float best[16];
+    int bidx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        best[i] = -INFINITY;
+        bidx[i] = 0;
+    }
+    f32x16 a, b;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = 0.f;
+    BFrag1 fr = read_bfrag1(smem, lr, 0, h);
+    const long Ml = M;
+    const unsigned pvoff = (unsigned)(4 * h) * (unsigned)M + (unsigned)(col0 + lr);   // per-lane part of the store offset
+
+    pipe_step_sim<0, 0, false, false>(smem, lr, h, areg, fr, a, b, best, bidx, 0, sim, 0u, Ml, apk);
+
+    for (int rb = g; rb < nrb; rb += G) {
+        const int row0 = rb * V2_ROWS + wave * 32;                        // uniform
+        float* pbase = sim + (long)row0 * Ml;
+        const bool has_next = rb + G < nrb;
+        const int nrow = (has_next ? (rb + G) * V2_ROWS : rb * V2_ROWS) + wave * 32 + lr;
+        const unsigned char* arow_next = apk + (long)nrow * ROW_BYTES;
+        const int gc = col0 + lr;
+        pipe_step_sim<1, 0, false, true>(smem, lr, h, areg, fr, b, a, best, bidx, gc, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<2, 1, false, true>(smem, lr, h, areg, fr, a, b, best, bidx, gc + 32, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<3, 2, false, true>(smem, lr, h, areg, fr, b, a, best, bidx, gc + 64, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<4, 3, false, true>(smem, lr, h, areg, fr, a, b, best, bidx, gc + 96, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<5, 4, false, true>(smem, lr, h, areg, fr, b, a, best, bidx, gc + 128, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<6, 5, false, true>(smem, lr, h, areg, fr, a, b, best, bidx, gc + 160, pbase, pvoff, Ml, arow_next);
+        pipe_step_sim<7, 6, true, true>(smem, lr, h, areg, fr, b, a, best, bidx, gc + 192, pbase, pvoff, Ml, arow_next);
+        if (has_next) {
+            pipe_step_sim<0, 7, false, true>(smem, lr, h, areg, fr, a, b, best, bidx, gc + 224, pbase, pvoff, Ml, arow_next);
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = b[reg];
+                const bool t = v > best[reg];
+                best[reg] = t ? v : best[reg];
+                bidx[reg] = t ? gc + 224 : bidx[reg];
+                float* o = pbase + (long)((reg & 3) + 8 * (reg >> 2)) * Ml + 224;
+                __builtin_nontemporal_store(v, o + pvoff);
+            }
+        }
+        finalize_rows(best, bidx, lane, h, row0, R, panel, pval, pidx);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            best[i] = -INFINITY;
+            bidx[i] = 0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void merge_splits_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                            int splits, int R, float* __restrict__ oval, int32_t* __restrict__ oidx)
 {
@@ -527,12 +963,14 @@ int pick_splits(int R, int M, bool write_sim)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// 1 = tile-streaming kernel, 2 = LDS-resident panel kernel (default); GDM_MATCH_KERNEL overrides, for A/B runs.
+// 1 = tile-streaming kernel, 2 = LDS-resident panel kernel, 3 (default) = 2 + in-wave software pipeline where the shape allows;
+// GDM_MATCH_KERNEL overrides, for A/B runs.
 int match_kernel_version()
 {
     const char* e = getenv("GDM_MATCH_KERNEL");
     if (e && e[0] == '1') return 1;
-    return 2;
+    if (e && e[0] == '2') return 2;
+    return 3;
 }
 
 } // namespace
@@ -592,10 +1030,16 @@ extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_ro
     int rc;
     const int panels = gdm_cdiv(M, PANEL_COLS);
     int nsplit;
-    if (match_kernel_version() == 2 && panels <= 64) {
+    const int mkv = match_kernel_version();
+    if (mkv >= 2 && panels <= 64) {
         // ---- v2: LDS-resident model panel, one persistent-ish workgroup per (panel, row group) ----
         const int nrb = gdm_cdiv(R, V2_ROWS);
-        int G = 512 / panels;                                   // ~2 workgroups' worth of work per CU queue
+        const bool pipe = mkv == 3 && precision == GDM_MATCH_BF16X3 && R % V2_ROWS == 0 && M % PANEL_COLS == 0 &&
+                          (long)R * M < (1L << 40) && (long)32 * M < (1L << 30);
+        // one workgroup per CU (the panel takes the LDS): v2 queues two rounds; v3 runs one round of <= 256 workgroups,
+        // which the store path prefers (tools/micro/store_pattern.hip: 5.9 vs 4.9 TB/s)
+        int G = (pipe ? 256 : 512) / panels;
+        if (const char* ge = getenv("GDM_MATCH_G")) G = atoi(ge);
         if (G < 1) G = 1;
         if (G > nrb) G = nrb;
         if (G >= 8) G &= ~7;                                    // keep same-rows workgroups on one bid%8 class
@@ -609,10 +1053,15 @@ extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_ro
             (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_BF16X3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
             (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
             (void)hipFuncSetAttribute((const void*)match_panel_kernel<GDM_MATCH_F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_pipe_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+            (void)hipFuncSetAttribute((const void*)match_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
             attr_set = true;
         }
 #define LAUNCH2(P, W) hipLaunchKernelGGL((match_panel_kernel<P, W>), grid, dim3(V2_THREADS), PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi)
-        if (precision == GDM_MATCH_BF16X3) {
+        if (pipe) {
+            if (ws_sim) hipLaunchKernelGGL(match_pipe_sim_kernel, grid, dim3(V2_THREADS), PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi);
+            else hipLaunchKernelGGL(match_pipe_kernel, grid, dim3(V2_THREADS), PANEL_BYTES, stream, apk, bpk, R, M, G, sim, ov, oi);
+        } else if (precision == GDM_MATCH_BF16X3) {
             if (ws_sim) LAUNCH2(GDM_MATCH_BF16X3, true); else LAUNCH2(GDM_MATCH_BF16X3, false);
         } else {
             if (ws_sim) LAUNCH2(GDM_MATCH_F32, true); else LAUNCH2(GDM_MATCH_F32, false);

@@ -199,13 +199,33 @@ def test_match_vs_oracle(ops, prec, B, N, M):
     assert torch.equal(gs.max(dim=2)[0], gv)
 
 
-def test_match_first_max_on_exact_ties(ops):
+@pytest.mark.parametrize("prec", [0, 1])
+def test_match_first_max_on_exact_ties(ops, prec):
     """Duplicate model vertices give exactly equal similarities: the lowest index must win (torch.max CPU)."""
     rs = np.random.RandomState(0)
     scene, model = _desc(rs, 1, 256, 512)
     model[:, 300:] = model[:, :212]
-    gi, gv = ops.match(scene.cuda(), model.cuda(), precision=1)
+    gi, gv = ops.match(scene.cuda(), model.cuda(), precision=prec)
     assert (gi.cpu() < 300).all()
+    gi2, gv2, _ = ops.match(scene.cuda(), model.cuda(), precision=prec, return_sim=True)
+    assert torch.equal(gi, gi2) and torch.equal(gv, gv2)
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 256, 256), (2, 1024, 4096), (5, 512, 2304), (16, 2048, 8192)])
+def test_match_pipelined_kernels_equal_panel_kernel(ops, B, N, M, monkeypatch):
+    """The software-pipelined kernels (default where R % 256 == 0 and M % 256 == 0) run the same products in the same
+    order as the plain LDS-panel kernel: indices, maxima and the matrix are bit-identical."""
+    scene, model = _desc(np.random.RandomState(B + N + M), B, N, M)
+    scene, model = scene.cuda(), model.cuda()
+    monkeypatch.setenv("GDM_MATCH_KERNEL", "2")
+    ri, rv, rs_ = ops.match(scene, model, precision=0, return_sim=True)
+    ri2, rv2 = ops.match(scene, model, precision=0)
+    monkeypatch.delenv("GDM_MATCH_KERNEL")
+    gi, gv, gs = ops.match(scene, model, precision=0, return_sim=True)
+    gi2, gv2 = ops.match(scene, model, precision=0)
+    assert torch.equal(ri, gi) and torch.equal(rv, gv) and torch.equal(rs_, gs)
+    assert torch.equal(ri2, gi2) and torch.equal(rv2, gv2)
+    assert torch.equal(gi, gi2) and torch.equal(gv, gv2)
 
 
 def test_seg_mask(ops):

@@ -19,7 +19,7 @@ for prec, pname in ((0, "bf16x3"), (1, "f32")):
     outs = {}
     times = {}
     for rnd in range(5):
-        for ver in ("1", "2"):
+        for ver in ("2", "3"):
             os.environ["GDM_MATCH_KERNEL"] = ver
             for mode in ("fused", "mat"):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,8 +35,8 @@ for prec, pname in ((0, "bf16x3"), (1, "f32")):
         ms = np.median(times[k][1:])
         extra = ("%.0f GB/s (%.1f%% of 8 TB/s)" % (mat_bytes / ms / 1e6, mat_bytes / ms / 1e6 / 80)) if k[1] == "mat" else ""
         print("%-7s v%s %-5s %8.1f us  %7.1f TF/s algorithmic  %s" % (pname, k[0], k[1], ms * 1e3, flops / ms / 1e9, extra))
-    same_idx = torch.equal(outs[("1", "fused")][0], outs[("2", "fused")][0])
-    dv = (outs[("1", "fused")][1] - outs[("2", "fused")][1]).abs().max().item()
-    ds = (outs[("1", "mat")][2] - outs[("2", "mat")][2]).abs().max().item()
-    print("   v1 vs v2: idx equal=%s  max|dval|=%.2e  max|dsim|=%.2e  fused==mat idx: %s" %
+    same_idx = torch.equal(outs[("3", "fused")][0], outs[("2", "fused")][0])
+    dv = (outs[("3", "fused")][1] - outs[("2", "fused")][1]).abs().max().item()
+    ds = (outs[("3", "mat")][2] - outs[("2", "mat")][2]).abs().max().item()
+    print("   v3 vs v2: idx equal=%s  max|dval|=%.2e  max|dsim|=%.2e  fused==mat idx: %s" %
           (same_idx, dv, ds, torch.equal(outs[("2", "fused")][0], outs[("2", "mat")][0])))
