@@ -126,21 +126,21 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     // packed row of (b, y, x0 + lr) for tap (0,0): padded coords (y + ky, x + kx), ky,kx in 0..2
     const long rowbase = (((long)b * (H + 2) + y) * (W + 2) + x0 + lr) * nchunk;
 
-    // A operand in two halves of the 128-channel chunk (k-steps 0-3 / 4-7): a half's registers are reloaded with the
-    // NEXT panel's data as soon as the current panel is done with them, so the prefetch needs no second register set
-    // (64 + 64 VGPRs would not fit beside the accumulators at 2 waves per SIMD).
+    // A operand: 8 k-steps x (hi, lo) fragments = 64 VGPRs, single-buffered.  The loop is k-step major (12 MFMAs over the
+    // four 32-channel output blocks per k-step), so a k-step's registers are dead right after it and are reloaded with the
+    // NEXT panel's data there and then -- except the last two k-steps, whose reload waits for the top of the next iteration:
+    // hipcc drains vmcnt to 0 at a loop back-edge for loads consumed in the next iteration, so nothing may be issued late in
+    // the body (a load issued just before the back-edge exposes its whole latency to all 8 waves at once).
     u32x4 ahi[8], alo[8];                                           // fragments of k-step s: ahi[s], alo[s]
-    auto load_a_half = [&](int it, int half) {
+    auto a_row = [&](int it) {
         const int tap = (TAPS == 1) ? 4 : it / nchunk;
         const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
         const int ky = tap / 3, kx = tap - ky * 3;
-        const unsigned char* r = xpk + (rowbase + ((long)ky * (W + 2) + kx) * nchunk + chunk) * ROWB;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ss = half * 4 + s;
-            ahi[ss] = *reinterpret_cast<const u32x4*>(r + (2 * ss + h) * 16);
-            alo[ss] = *reinterpret_cast<const u32x4*>(r + (16 + 2 * ss + h) * 16);
-        }
+        return xpk + (rowbase + ((long)ky * (W + 2) + kx) * nchunk + chunk) * ROWB;
+    };
+    auto load_a = [&](const unsigned char* r, int ss) {
+        ahi[ss] = *reinterpret_cast<const u32x4*>(r + (2 * ss + h) * 16);
+        alo[ss] = *reinterpret_cast<const u32x4*>(r + (16 + 2 * ss + h) * 16);
     };
     u32x4 stage[8];
     auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
@@ -166,34 +166,70 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
+    constexpr int LATE = 2;                                         // k-steps whose reload is deferred to the next iteration's top
     stage_load(0);
     stage_store(0);
-    load_a_half(0, 0);
-    load_a_half(0, 1);
+    {
+        const unsigned char* r0 = a_row(0);
+#pragma unroll
+        for (int ss = 0; ss < 8 - LATE; ++ss) load_a(r0, ss);
+    }
     for (int it = 0; it < npanel; ++it) {
         __syncthreads();                                            // panel `it` is in LDS; panel it-1's readers are done
         const bool more = it + 1 < npanel;
         if (more) stage_load(it + 1);
+        const unsigned char* rcur = a_row(it);
+#pragma unroll
+        for (int ss = 8 - LATE; ss < 8; ++ss) load_a(rcur, ss);
+        const unsigned char* rnext = a_row(more ? it + 1 : it);
         const unsigned char* base = smem + (it & 1) * CV_PANEL;
+        // 16 units of (k-step s, output-block pair p): 6 MFMAs on this unit's fragments while the next unit's four fragment
+        // reads are in flight; sched_group_barrier pins MFMA : ds_read 1:1 and the operand reloads right behind their k-step
+        u32x4 fh[2], fl[2];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int j = 0; j < 2; ++j) {
+            fh[j] = *reinterpret_cast<const u32x4*>(base + swz(j * 32 + lr, h));
+            fl[j] = *reinterpret_cast<const u32x4*>(base + swz(j * 32 + lr, 16 + h));
+        }
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int col = cb * 32 + lr;
+        for (int u = 0; u < 16; ++u) {
+            const int s = u >> 1, pr = u & 1;
+            u32x4 nh[2], nl[2];
+            if (u < 15) {
+                const int sn = (u + 1) >> 1, pn = (u + 1) & 1;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int s = half * 4 + s4;
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + swz(col, 2 * s + h)));
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + swz(col, 16 + 2 * s + h)));
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[s]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, alo[s]);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    nh[j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 2 * sn + h));
+                    nl[j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 16 + 2 * sn + h));
                 }
             }
-            if (more) load_a_half(it + 1, half);                    // this half's registers are free now
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[s]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, alo[s]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fl[j]), acc[2 * pr + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
+            if (pr == 1 && s < 8 - LATE) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
+            if (u < 15) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fh[j] = nh[j];
+                    fl[j] = nl[j];
+                }
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (u < 15 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if ((u & 1) == 1 && (u >> 1) < 8 - LATE) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) stage_store((it + 1) & 1);
     }
 
