@@ -8,9 +8,9 @@
 //
 //   out[b,co,y,x] = act( scale[co] * sum_{tap,ci} W[co,ci,tap] * in[b,ci,y+ky-1,x+kx-1] + shift[co] (+ res) )
 //
-// Data layout: activations are re-packed once per layer (pack kernel below) into PIXEL-major rows with a one-pixel
-// zero border: row((b,yy,xx), chunk) = 128 bf16 hi | 128 bf16 lo of channels [128 chunk, 128 chunk + 128), so a tap
-// is just a row offset and the zero padding is real zeros.  Weights are packed once per weight change into
+// Data layout: activations are re-packed once per layer (pack kernel below) into bf16 hi / lo planes of 8 channels with a
+// one-pixel zero border (fragment-planar, see conv_pack_act_kernel), so a tap is just a pixel offset, the zero padding is
+// real zeros and every operand load of a wave is two contiguous 512-B runs.  Weights are packed once per weight change into
 // rows (tap, chunk, co) of the same 512-B format.  Then the kernel is the matching kernel's shape: a wave keeps
 // 32 pixels x 128 channels of one (tap, chunk) in 64 VGPRs as the MFMA A operand, 128 output channels of that
 // (tap, chunk) sit in a double-buffered, XOR-swizzled LDS panel as the B operand (global -> registers before the
@@ -29,6 +29,9 @@ constexpr int CV_THREADS = 512;           // 8 waves
 constexpr int CV_PIX = 256;               // pixels per workgroup (32 per wave)
 constexpr int CV_CO = 128;                // output channels per workgroup
 constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
+#ifndef GDM_CONV_EXP
+#define GDM_CONV_EXP 0                   // development: 1 = no weight staging / barrier after panel 0, 2 = no operand reloads (wrong results)
+#endif
 
 __device__ __forceinline__ unsigned short bf16_rne(float v)
 {
@@ -49,8 +52,11 @@ __device__ __forceinline__ void split8(const float* v, unsigned (&hi)[4], unsign
     }
 }
 
-// x f32[B,C,H,W] -> packed rows of the zero-bordered pixel grid: row = ((b*(H+2) + y+1)*(W+2) + x+1)*nchunk + chunk
-// one block: 64 consecutive pixels of one image row-major plane index x one 128-channel chunk
+// x f32[B,C,H,W] -> packed activations, PLANAR by 16-byte MFMA fragment: for every (b, 128-channel chunk) 32 planes of the
+// zero-bordered pixel grid, plane q < 16 = bf16 "hi" of channels [8q, 8q+8), plane 16+q = their "lo"; element (yy, xx) of a
+// plane is 16 B at ((b*nchunk + chunk)*32 + plane) * (H+2)(W+2) + yy*(W+2) + xx.  A wave's operand load (lane = pixel, one
+// fragment) is then two contiguous 512-B runs for ANY tap shift, instead of 32 scattered 32-B pieces of pixel-major rows.
+// one block: 64 consecutive pixels of one image x one 128-channel chunk
 __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restrict__ x, int C, int H, int W,
                                                             unsigned char* __restrict__ out)
 {
@@ -58,25 +64,25 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
     const int b = blockIdx.z, chunk = blockIdx.y;
     const int nchunk = C / 128;
     const int hw = H * W;
+    const long plane = (long)(H + 2) * (W + 2);
     const int p0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = min(p0 + lane, hw - 1);
     const float* xb = x + ((long)b * C + chunk * 128) * hw;
     for (int c = w; c < 128; c += 4) t[c][lane] = xb[(long)c * hw + p];
     __syncthreads();
-    for (int it = 0; it < 4; ++it) {
-        const int item = it * 256 + threadIdx.x;        // 64 pixels x 16 chunks of 8 channels
-        const int ch = item & 15, pl = item >> 4;
-        if (p0 + pl >= hw) continue;
+    const int pp = p0 + lane;
+    if (pp >= hw) return;
+    const int y = pp / W, xx = pp - y * W;
+    unsigned char* o = out + (((long)(b * nchunk + chunk) * 32) * plane + (long)(y + 1) * (W + 2) + xx + 1) * 16;
+    for (int q = w; q < 16; q += 4) {                    // consecutive lanes = consecutive pixels: 1-KiB contiguous stores
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = t[ch * 8 + j][pl];
+        for (int j = 0; j < 8; ++j) v[j] = t[q * 8 + j][lane];
         unsigned hi[4], lo[4];
         split8(v, hi, lo);
-        const int pp = p0 + pl, y = pp / W, xx = pp - y * W;
-        unsigned char* row = out + ((((long)b * (H + 2) + y + 1) * (W + 2) + xx + 1) * nchunk + chunk) * ROWB;
-        *reinterpret_cast<uint4*>(row + ch * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4*>(row + 256 + ch * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(o + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
 
@@ -123,8 +129,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     const int b = (int)(pc / hw);
     const int prem = (int)(pc - (long)b * hw);
     const int y = prem / W, x0 = prem - y * W;
-    // packed row of (b, y, x0 + lr) for tap (0,0): padded coords (y + ky, x + kx), ky,kx in 0..2
-    const long rowbase = (((long)b * (H + 2) + y) * (W + 2) + x0 + lr) * nchunk;
+    // this lane's pixel (b, y, x0 + lr) at tap (0,0) inside a plane of the packed activations: padded coords (y + ky, x + kx)
+    const long plane = (long)(H + 2) * (W + 2);
+    const long pixbase = (long)y * (W + 2) + x0 + lr;
 
     // A operand: 8 k-steps x (hi, lo) fragments = 64 VGPRs, single-buffered.  The loop is k-step major (12 MFMAs over the
     // four 32-channel output blocks per k-step), so a k-step's registers are dead right after it and are reloaded with the
@@ -136,11 +143,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
         const int tap = (TAPS == 1) ? 4 : it / nchunk;
         const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
         const int ky = tap / 3, kx = tap - ky * 3;
-        return xpk + (rowbase + ((long)ky * (W + 2) + kx) * nchunk + chunk) * ROWB;
+        return xpk + (((long)(b * nchunk + chunk) * 32 + h) * plane + pixbase + (long)ky * (W + 2) + kx) * 16;
     };
+    const long fstride = 2 * plane * 16;                            // fragment 2*ss+h -> 2*(ss+1)+h
     auto load_a = [&](const unsigned char* r, int ss) {
-        ahi[ss] = *reinterpret_cast<const u32x4*>(r + (2 * ss + h) * 16);
-        alo[ss] = *reinterpret_cast<const u32x4*>(r + (16 + 2 * ss + h) * 16);
+        ahi[ss] = *reinterpret_cast<const u32x4*>(r + ss * fstride);
+        alo[ss] = *reinterpret_cast<const u32x4*>(r + (8 + ss) * fstride);
     };
     u32x4 stage[8];
     auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
@@ -166,7 +174,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-    constexpr int LATE = 2;                                         // k-steps whose reload is deferred to the next iteration's top
+#ifndef GDM_CONV_LATE
+#define GDM_CONV_LATE 2
+#endif
+    constexpr int LATE = GDM_CONV_LATE;                                         // k-steps whose reload is deferred to the next iteration's top
     stage_load(0);
     stage_store(0);
     {
@@ -175,16 +186,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
         for (int ss = 0; ss < 8 - LATE; ++ss) load_a(r0, ss);
     }
     for (int it = 0; it < npanel; ++it) {
-        __syncthreads();                                            // panel `it` is in LDS; panel it-1's readers are done
+        if (!(GDM_CONV_EXP & 1) || it == 0) __syncthreads();       // panel `it` is in LDS; panel it-1's readers are done
         const bool more = it + 1 < npanel;
-        if (more) stage_load(it + 1);
         const unsigned char* rcur = a_row(it);
-#pragma unroll
-        for (int ss = 8 - LATE; ss < 8; ++ss) load_a(rcur, ss);
         const unsigned char* rnext = a_row(more ? it + 1 : it);
-        const unsigned char* base = smem + (it & 1) * CV_PANEL;
+        const unsigned char* base = smem + ((GDM_CONV_EXP & 1) ? 0 : (it & 1)) * CV_PANEL;
         // 16 units of (k-step s, output-block pair p): 6 MFMAs on this unit's fragments while the next unit's four fragment
-        // reads are in flight; sched_group_barrier pins MFMA : ds_read 1:1 and the operand reloads right behind their k-step
+        // reads are in flight
         u32x4 fh[2], fl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -211,7 +219,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
             for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
-            if (pr == 1 && s < 8 - LATE) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
+            if (pr == 1 && s < 8 - LATE && !(GDM_CONV_EXP & 2)) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
+            if (u == 0) {
+                // issued BEHIND the first MFMAs: the wait hipcc puts in front of them for the loop-carried operand registers
+                // is a vmcnt(0), and must not find this iteration's loads already in flight
+                if (more && !(GDM_CONV_EXP & 1)) stage_load(it + 1);
+                if (!(GDM_CONV_EXP & 2) || it == 0) {
+#pragma unroll
+                    for (int ss = 8 - LATE; ss < 8; ++ss) load_a(rcur, ss);
+                }
+            }
             if (u < 15) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -219,18 +236,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
                     fl[j] = nl[j];
                 }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
+            // one scheduling region per unit (the scheduler otherwise regroups the MFMAs accumulator-major, which pulls the
+            // late operand loads to the front); inside it: MFMA : ds_read 1:1, the operand reloads behind the MFMAs
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (u < 15 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            if ((u & 1) == 1 && (u >> 1) < 8 - LATE) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) stage_store((it + 1) & 1);
+        if (more && !(GDM_CONV_EXP & 1)) stage_store((it + 1) & 1);
     }
 
     // ---- epilogue: lane = output channel (col), registers = pixels; 4 consecutive pixels per register quad -> 16-B stores ----
