@@ -86,21 +86,23 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
     }
 }
 
-// w f32[Cout,Cin,3,3] -> rows ((tap*nchunk + chunk)*Cout + co): channels [128 chunk, +128) of tap (ky,kx)
+// w f32[Cout,Cin,3,3] -> rows ((tap*nchunk + chunk)*CoutP + co): channels [128 chunk, +128) of tap (ky,kx); CoutP = Cout rounded
+// up to 128, rows co >= Cout are zero (a workgroup always stages 128 rows)
 __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, unsigned char* __restrict__ out)
 {
     const int nchunk = Cin / 128;
+    const int CoutP = (Cout + 127) & ~127;
     const long item = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 16 groups of 8 channels)
-    const long rows = (long)taps * nchunk * Cout;
+    const long rows = (long)taps * nchunk * CoutP;
     if (item >= rows * 16) return;
     const int ch = (int)(item & 15);
     const long row = item >> 4;
-    const int co = (int)(row % Cout);
-    const int tc = (int)(row / Cout);
+    const int co = (int)(row % CoutP);
+    const int tc = (int)(row / CoutP);
     const int chunk = tc % nchunk, tap = tc / nchunk;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap];
+    for (int j = 0; j < 8; ++j) v[j] = co < Cout ? w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap] : 0.f;
     unsigned hi[4], lo[4];
     split8(v, hi, lo);
     unsigned char* r = out + row * ROWB;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     };
     u32x4 stage[8];
     auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
-        const unsigned char* src = wpk + ((long)it * Cout + co0) * ROWB;
+        const unsigned char* src = wpk + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = i * CV_THREADS + tid;
@@ -304,20 +306,20 @@ extern "C" size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W)
 extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
 {
     if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
-    return (size_t)9 * (Cin / 128) * Cout * ROWB;
+    return (size_t)9 * (Cin / 128) * ((Cout + 127) & ~127) * ROWB;
 }
 
 extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
 {
     if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
-    return (size_t)(Cin / 128) * Cout * ROWB;
+    return (size_t)(Cin / 128) * ((Cout + 127) & ~127) * ROWB;
 }
 
 static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who)
 {
     GDM_CHECK_ARG(w && wpk, "%s: NULL pointer", who);
     GDM_CHECK_ARG(Cout >= 1 && Cin >= 128 && Cin % 128 == 0, "%s: Cout=%d Cin=%d (Cin %% 128 == 0)", who, Cout, Cin);
-    const long items = (long)taps * (Cin / 128) * Cout * 16;
+    const long items = (long)taps * (Cin / 128) * ((Cout + 127) & ~127) * 16;
     hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk);
     return gdm_launch_status("conv_pack_w_kernel");
 }
@@ -373,11 +375,11 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
                                       int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream)
 {
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
-    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
+    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128)", Cin, Cout);
     GDM_CHECK_ARG(W % 32 == 0 && H >= 1, "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32", W);
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
-    dim3 grid(gdm_cdiv(ptot, CV_PIX), Cout / CV_CO);
+    dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));       // the last block's rows beyond Cout are zero weights, never stored
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {

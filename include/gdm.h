@@ -258,7 +258,8 @@ int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, floa
 
 /* 1x1 convolution / GEMM on the same split-bf16 MFMA kernel (one tap): x packed by gdm_conv3x3_pack_act_hip, weights
  * f32[Cout,Cin] packed by gdm_conv1x1_pack_weight_hip.  out = act(scale*(W x)+shift) as f32[B,Cout,H,W], or, with
- * pixel_major != 0, as f32[B*H*W, Cout] (used for the dense part of SplineConv: nodes x (125*128)). */
+ * pixel_major != 0, as f32[B*H*W, Cout] (used for the dense part of SplineConv: nodes x (125*128)).  Cin % 128 == 0; Cout is
+ * arbitrary: the packed weights carry zero rows up to the next multiple of 128 and the extra outputs are never stored. */
 size_t gdm_conv1x1_weight_bytes(int Cout, int Cin);
 int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream);
 int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,

@@ -44,7 +44,7 @@ def main():
                     "%.2f" % (v[2] / 1e3), "%.2f" % (v[3] / 1e3), "%.2f" % (100.0 * v[0] / busy)])
     # roofline loop kernels (after the window)
     tail = rows[e:]
-    for name in ("match_panel_kernel<0, true>", "match_panel_kernel<1, true>", "match_kernel<0, true>", "match_kernel<1, true>"):
+    for name in ("match_pipe_sim_kernel", "match_panel_kernel<0, true>", "match_panel_kernel<1, true>", "match_kernel<0, true>", "match_kernel<1, true>"):
         ds = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail if name in r["Kernel_Name"]]
         if ds:
             w.writerow(["# roofline loop: %s calls=%d avg_us=%.2f min_us=%.2f" % (name, len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3)])
