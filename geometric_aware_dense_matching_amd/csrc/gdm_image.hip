@@ -344,6 +344,42 @@ __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float*
     }
 }
 
+// The same fusion tail with the pixel half of the convolution inside: y[b,co,j] = act(scale[co] * (sum_ci W[co,ci] x[b,ci,j]
+// + t[b,co,idx[b,j]]) + shift[co]) for the 64-channel levels (ffb6d.py:216-222 at ds stage 0, :252-258 at up stages 1-2), where
+// the GEMM has K = 64: hipBLASLt's f32 kernel runs it at ~0.5 TB/s (62 us per call) and the intermediate costs a write + a read.
+// One pass, thread = pixel, 64 accumulators in registers, W^T rows as wave-uniform scalar loads; exact fp32 FMAs.
+template <int C, int ACT>
+__global__ __launch_bounds__(256) void conv1x1_gather_add_act_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                     const float* __restrict__ t, const int32_t* __restrict__ idx,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     int n, long m, float slope, float* __restrict__ y)
+{
+    const int b = blockIdx.y;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    int src = idx[(long)b * m + j];
+    src = min(max(src, 0), n - 1);
+    const float* xb = x + (long)b * C * m + j;
+    const float* tb = t + (long)b * C * n + src;
+    float acc[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) acc[co] = tb[(long)co * n];
+#pragma unroll 4
+    for (int ci = 0; ci < C; ++ci) {
+        const float xv = xb[(long)ci * m];
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc[co] = fmaf(wt[ci * C + co], xv, acc[co]);
+    }
+    float* yb = y + (long)b * C * m + j;
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+        float o = scale[co] * acc[co] + shift[co];
+        if (ACT == 1) o = fmaxf(o, 0.f);
+        if (ACT == 2) o = o > 0.f ? o : o * slope;
+        yb[(long)co * m] = o;
+    }
+}
+
 // `final` = Conv2d(64,64,1) + LogSoftmax(dim=1) (pspnet.py:108-112), applied at 128x128 and 256x256 (ffb6d.py:79-80):
 // one pass instead of a GEMM + bias + spatial-softmax (313 + 136 us at 256x256, batch 16).  HBM-bound (read C, write C
 // floats per pixel); a thread owns one pixel, keeps the C output channels in registers, weights arrive as wave-uniform
@@ -543,6 +579,20 @@ extern "C" int gdm_gather_add_affine_act_hip(const float* x, const float* t, con
     else if (act == 1) hipLaunchKernelGGL(gather_add_affine_act_kernel<1>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
     else hipLaunchKernelGGL(gather_add_affine_act_kernel<2>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
     return gdm_launch_status("gather_add_affine_act_kernel");
+}
+
+extern "C" int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
+                                              const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream)
+{
+    GDM_CHECK_ARG(x && wt && t && idx && scale && shift && y, "gdm_conv1x1_gather_add_act_hip: NULL pointer");
+    GDM_CHECK_ARG(C == 64, "gdm_conv1x1_gather_add_act_hip: C=%d, only the 64-channel fusion levels are built", C);
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1 && m >= 1 && act >= 0 && act <= 2, "gdm_conv1x1_gather_add_act_hip: bad shape");
+    dim3 grid(gdm_cdiv(m, 256), B);
+    hipStream_t s = (hipStream_t)stream;
+    if (act == 0) hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 0>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
+    else if (act == 1) hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 1>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
+    else hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 2>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
+    return gdm_launch_status("conv1x1_gather_add_act_kernel");
 }
 
 extern "C" int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream)

@@ -784,6 +784,9 @@ __device__ __forceinline__ void finalize_rows(const float (&best)[16], const int
 // 2 rows x 128 contiguous bytes and may stay non-temporal; the swapped layout's 16-byte pieces need write-back merging in L2
 // and lose under load (347 vs 256 us).  Running (max, arg) per register, v2's butterfly per row block.
 // Steps of 32 columns (one accumulator in flight, one draining): 24 MFMAs | 16 values drained per step.
+#ifndef GDM_MATCH_EXP
+#define GDM_MATCH_EXP 0     // development: 1 = no operand reload, 2 = no matrix stores (wrong results)
+#endif
 struct BFrag1 { u32x4 h, l; };
 
 __device__ __forceinline__ BFrag1 read_bfrag1(const unsigned char* smem, int c, int s, int h)
@@ -813,7 +816,7 @@ __device__ __forceinline__ void pipe_step_sim(const unsigned char* smem, int lr,
         n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, n, 0, 0, 0);
         n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, n, 0, 0, 0);
         n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, n, 0, 0, 0);
-        if (RELOAD) {
+        if (RELOAD && !(GDM_MATCH_EXP & 1)) {
             areg[s] = *reinterpret_cast<const u32x4*>(arow_next + (2 * s + h) * 16);
             areg[8 + s] = *reinterpret_cast<const u32x4*>(arow_next + (16 + 2 * s + h) * 16);
         }
@@ -827,7 +830,7 @@ __device__ __forceinline__ void pipe_step_sim(const unsigned char* smem, int lr,
             best[reg] = t ? v : best[reg];
             bidx[reg] = t ? pgc : bidx[reg];
             float* o = pbase + (long)((reg & 3) + 8 * (reg >> 2)) * M + PCP * 32;     // uniform row base, per-lane 32-bit offset
-            __builtin_nontemporal_store(v, o + pvoff);
+            if (!(GDM_MATCH_EXP & 2)) __builtin_nontemporal_store(v, o + pvoff);
         }
     }
 #pragma unroll

@@ -110,6 +110,15 @@ class FFB6DEmb(nn.Module):
             layer.__dict__["_gdm_split"] = cache
         return cache[1], cache[2]
 
+    @staticmethod
+    def _fuse_weight_t(layer, wa):
+        """wa transposed ([ci][co], contiguous), cached beside the split weights."""
+        cache = layer.__dict__.get("_gdm_wa_t")
+        if cache is None or cache[0] is not wa:
+            cache = (wa, wa.t().contiguous())
+            layer.__dict__["_gdm_wa_t"] = cache
+        return cache[1]
+
     def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx):
         """fuse(cat(rgb_emb0, nearest_interp(pre(p_emb0)))) (ffb6d.py:216-222,252-258).  Eval: the point half of the
         1x1 fuse convolution runs at the points (a 1x1 conv commutes with the gather), the pixel half is a GEMM with half
@@ -120,6 +129,12 @@ class FFB6DEmb(nn.Module):
             if code is not None:
                 wa, wb = self._split_fuse_weight(fuse_layer, c)
                 t = torch.matmul(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
+                if c == 64 and wa.shape[0] == 64:
+                    # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)
+                    scale, shift = folded_bn(fuse_layer.normlayer.bn)
+                    y = ops.conv1x1_gather_add_act(rgb_emb0.reshape(bs, c, hr * wr), self._fuse_weight_t(fuse_layer, wa), t,
+                                                   idx.reshape(bs, -1), scale, shift, code[0], code[1])
+                    return y.view(bs, -1, hr, wr)
                 if USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
                     wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
                     x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA

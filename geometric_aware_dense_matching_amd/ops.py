@@ -397,6 +397,23 @@ def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     return x
 
 
+def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
+    """y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]) in one pass for the 64-channel fusion
+    levels.  x f32[B,64,m], wt f32[64,64] = W transposed (contiguous), t f32[B,64,n], idx int[B,m(,1)].  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    t = _dev(t, torch.float32, "t")
+    wt = _dev(wt, torch.float32, "wt")
+    idx = _idx32(idx, "idx")
+    B, C, m = x.shape
+    if C != 64 or tuple(wt.shape) != (64, 64) or t.shape[1] != 64:
+        raise ValueError("conv1x1_gather_add_act: built for 64 -> 64 channels, got x %s wt %s t %s" % (tuple(x.shape), tuple(wt.shape), tuple(t.shape)))
+    y = torch.empty_like(x)
+    check(_lib.lib().gdm_conv1x1_gather_add_act_hip(x.data_ptr(), wt.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
+                                                    shift.data_ptr(), B, C, t.shape[2], m, act, float(slope), y.data_ptr(), _stream()),
+          "gdm_conv1x1_gather_add_act_hip")
+    return y
+
+
 _final_wt_cache = {}
 
 

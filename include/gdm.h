@@ -234,6 +234,10 @@ int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2
  * x f32[B,C,m] (pixel half of the 1x1 conv), t f32[B,C,n] (point half, computed at the points), idx i32[B,m]. May run in place. */
 int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
                                   int B, int C, int n, int m, int act, float slope, float* y, void* stream);
+/* The same tail with the pixel half of the 1x1 convolution inside, for the 64-channel levels (C == 64):
+ * y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]); wt f32[C,C] = W transposed ([ci][co]). */
+int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
+                                   const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate),

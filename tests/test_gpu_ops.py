@@ -389,3 +389,24 @@ def test_gemm_bf16x3(ops, B, Cin, Cout, n):
     assert (got.double() - ref).abs().max().item() < tol
     got_pm = ops.gemm_bf16x3(x.cuda(), wpk, Cout, pixel_major=True).cpu().view(B, n, Cout).transpose(1, 2)
     assert (got_pm.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv1x1_gather_add_act(ops, act):
+    """64-channel point->pixel fusion tail in one pass == GEMM + gather + add + affine + activation in torch (fp64)."""
+    rs = np.random.RandomState(act)
+    B, C, m, n = 2, 64, 1000, 37
+    x = torch.from_numpy(rs.randn(B, C, m).astype(np.float32))
+    w = torch.from_numpy((rs.randn(C, C) / 8).astype(np.float32))
+    t = torch.from_numpy(rs.randn(B, C, n).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, n, (B, m)).astype(np.int32))
+    scale = torch.from_numpy(rs.rand(C).astype(np.float32) + 0.5)
+    shift = torch.from_numpy(rs.randn(C).astype(np.float32))
+    pre = torch.matmul(w.double(), x.double()) + torch.gather(t.double(), 2, idx.long().unsqueeze(1).expand(B, C, m))
+    ref = scale.double()[None, :, None] * pre + shift.double()[None, :, None]
+    if act == 1:
+        ref = ref.clamp(min=0)
+    if act == 2:
+        ref = torch.where(ref > 0, ref, ref * 0.2)
+    got = ops.conv1x1_gather_add_act(x.cuda(), w.t().contiguous().cuda(), t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2).cpu()
+    assert (got.double() - ref).abs().max().item() < 2e-5
