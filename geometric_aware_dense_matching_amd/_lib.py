@@ -58,6 +58,7 @@ SIGNATURES = {
     "gdm_circle_rows_bwd_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "gdm_kabsch_stats_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "gdm_kabsch_solve_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "gdm_lfa_stage_hip": (_i, [_vp] * 13 + [_i, _i, _i, _i, _i, _f, _vp, _vp]),
     "gdm_affine_act_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, ctypes.c_long, _i, _f, _vp, _vp]),
     "gdm_upconv3x3_gather_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "gdm_psp_combine_hip": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

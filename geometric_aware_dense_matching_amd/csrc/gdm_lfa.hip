@@ -1,0 +1,184 @@
+// RandLA-Net local feature aggregation, one attentive-pooling stage per launch, gfx950 (inference).
+//
+// Replaces, per stage, the chain of /root/reference/models/RandLA/RandLANet.py:
+//   relative_pos_encoding :720-727  ->  mlp1 (10 -> d/2, BN, LeakyReLU) :702  [-> mlp2 (d/2 -> d/2) :713 in the second stage]
+//   gather_neighbour :729-738       ->  cat([f_neighbours, f_xyz]) :705/:716
+//   Att_pooling.forward :747-754        fc (d x d, no bias), softmax over K, feature * score, sum over K, mlp (d -> out, BN, LeakyReLU)
+// The reference (and the unfused path of this package) materialises five [B, d, n, K] tensors per stage for these steps (gathered
+// features, encoded positions, their concat, the attention logits, the softmax) -- the memory-bound part of SURVEY.md row a4.
+// Here a stage reads the point features [B, d/2, n], xyz and the neighbour index once, keeps the d x K block of a point in LDS
+// and writes [B, out, n]; nothing of size n*K goes to HBM.  Two launches per Building_block instead of eighteen.
+//
+// Thread = (point slot p, channel c): a workgroup of 256 threads owns 256/D points.  Weights come pre-transposed ([in][out]),
+// so the load of W^T[j][c] is contiguous over c; the d x K block is broadcast-read from LDS as 16-byte quads; the softmax over
+// K and the weighted sum are in-thread (att_pool_kernel's arithmetic, same order).  Exact fp32 FMAs; K = 16.
+#include "gdm_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int LK = 16;
+
+struct LfaArgs {
+    const float* xyz;      // [B, n, 3]
+    const int32_t* idx;    // [B, n, 16]
+    const float* feat;     // [B, D/2, n]
+    const float* w1t;      // [10, D/2]        mlp1 weight transposed
+    const float* s1;       // [D/2]            folded BN scale / shift
+    const float* b1;
+    const float* w2t;      // [D/2, D/2] or NULL (first stage)
+    const float* s2;
+    const float* b2;
+    const float* wft;      // [D, D]           Att_pooling.fc transposed
+    const float* wmt;      // [D, OUT]         Att_pooling.mlp transposed
+    const float* sm;       // [OUT]
+    const float* bm;
+    float* out;            // [B, OUT, n]
+    int n, OUT;
+    float slope;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int D>
+__global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
+{
+    constexpr int H = D / 2;
+    constexpr int P = 256 / D;                         // points per workgroup
+    __shared__ __attribute__((aligned(16))) float fcat[P][D][LK];
+    __shared__ __attribute__((aligned(16))) float fx1[P][H][LK];
+    __shared__ float pe[P][10][LK];
+    __shared__ int nidx[P][LK];
+    __shared__ float aggv[P][D];
+
+    const int tid = threadIdx.x;
+    const int p = tid / D, c = tid - p * D;
+    const int b = blockIdx.y;
+    const int n = a.n;
+    const int i = min((int)blockIdx.x * P + p, n - 1);
+    const bool live = (int)blockIdx.x * P + p < n;
+    const float slope = a.slope;
+
+    // 1. relative position encoding of the 16 neighbours (rel_pos_enc_kernel's arithmetic)
+    if (c < LK) {
+        int jn = a.idx[((long)b * n + i) * LK + c];
+        jn = min(max(jn, 0), n - 1);
+        const float* pi = a.xyz + ((long)b * n + i) * 3;
+        const float* pj = a.xyz + ((long)b * n + jn) * 3;
+        const float ax = pi[0], ay = pi[1], az = pi[2];
+        const float bx = pj[0], by = pj[1], bz = pj[2];
+        const float rx = __fsub_rn(ax, bx), ry = __fsub_rn(ay, by), rz = __fsub_rn(az, bz);
+        float s = __fmul_rn(rx, rx);
+        s = __fadd_rn(s, __fmul_rn(ry, ry));
+        s = __fadd_rn(s, __fmul_rn(rz, rz));
+        pe[p][0][c] = __fsqrt_rn(s);
+        pe[p][1][c] = rx; pe[p][2][c] = ry; pe[p][3][c] = rz;
+        pe[p][4][c] = ax; pe[p][5][c] = ay; pe[p][6][c] = az;
+        pe[p][7][c] = bx; pe[p][8][c] = by; pe[p][9][c] = bz;
+        nidx[p][c] = jn;
+    }
+    __syncthreads();
+
+    // 2. mlp1 on the encoding and the neighbour gather: thread (j, half of K) fills 8 entries of each
+    const int j = c % H, kb = (c / H) * 8;
+    {
+        float w[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) w[q] = a.w1t[q * H + j];
+        const float sc = a.s1[j], sh = a.b1[j];
+        const float* frow = a.feat + ((long)b * H + j) * n;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kb + kk;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) v = fmaf(w[q], pe[p][q][k], v);
+            v = lrelu(fmaf(v, sc, sh), slope);
+            if (a.w2t) fx1[p][j][k] = v;
+            else fcat[p][H + j][k] = v;
+            fcat[p][j][k] = frow[nidx[p][k]];
+        }
+    }
+    __syncthreads();
+    if (a.w2t) {                                        // second stage: mlp2 on the encoded positions
+        float acc[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc[kk] = 0.f;
+        for (int q = 0; q < H; ++q) {
+            const float w = a.w2t[q * H + j];
+            const float4 f0 = *reinterpret_cast<const float4*>(&fx1[p][q][kb]);
+            const float4 f1 = *reinterpret_cast<const float4*>(&fx1[p][q][kb + 4]);
+            acc[0] = fmaf(w, f0.x, acc[0]); acc[1] = fmaf(w, f0.y, acc[1]); acc[2] = fmaf(w, f0.z, acc[2]); acc[3] = fmaf(w, f0.w, acc[3]);
+            acc[4] = fmaf(w, f1.x, acc[4]); acc[5] = fmaf(w, f1.y, acc[5]); acc[6] = fmaf(w, f1.z, acc[6]); acc[7] = fmaf(w, f1.w, acc[7]);
+        }
+        const float sc = a.s2[j], sh = a.b2[j];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) fcat[p][H + j][kb + kk] = lrelu(fmaf(acc[kk], sc, sh), slope);
+        __syncthreads();
+    }
+
+    // 3. attention logits of channel c for the 16 neighbours: att[k] = sum_j Wf[c][j] * fcat[j][k]
+    float att[LK];
+#pragma unroll
+    for (int k = 0; k < LK; ++k) att[k] = 0.f;
+#pragma unroll 2
+    for (int jj = 0; jj < D; ++jj) {
+        const float w = a.wft[jj * D + c];
+        const float4* fr = reinterpret_cast<const float4*>(&fcat[p][jj][0]);
+        const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3];
+        att[0] = fmaf(w, f0.x, att[0]); att[1] = fmaf(w, f0.y, att[1]); att[2] = fmaf(w, f0.z, att[2]); att[3] = fmaf(w, f0.w, att[3]);
+        att[4] = fmaf(w, f1.x, att[4]); att[5] = fmaf(w, f1.y, att[5]); att[6] = fmaf(w, f1.z, att[6]); att[7] = fmaf(w, f1.w, att[7]);
+        att[8] = fmaf(w, f2.x, att[8]); att[9] = fmaf(w, f2.y, att[9]); att[10] = fmaf(w, f2.z, att[10]); att[11] = fmaf(w, f2.w, att[11]);
+        att[12] = fmaf(w, f3.x, att[12]); att[13] = fmaf(w, f3.y, att[13]); att[14] = fmaf(w, f3.z, att[14]); att[15] = fmaf(w, f3.w, att[15]);
+    }
+    // 4. softmax over K, feature * score, sum over K (att_pool_kernel's order)
+    {
+        float mx = att[0];
+#pragma unroll
+        for (int k = 1; k < LK; ++k) mx = fmaxf(mx, att[k]);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < LK; ++k) {
+            att[k] = expf(att[k] - mx);
+            den += att[k];
+        }
+        float num = 0.f;
+#pragma unroll
+        for (int k = 0; k < LK; ++k) num += fcat[p][c][k] * (att[k] / den);
+        aggv[p][c] = num;
+    }
+    __syncthreads();
+
+    // 5. mlp on the pooled feature: out[c] = lrelu(sm[c] * sum_j Wm[c][j] agg[j] + bm[c])
+    const int OUT = a.OUT;
+    if (c < OUT) {
+        float o = 0.f;
+#pragma unroll 4
+        for (int jj = 0; jj < D; ++jj) o = fmaf(a.wmt[jj * OUT + c], aggv[p][jj], o);
+        o = lrelu(fmaf(o, a.sm[c], a.bm[c]), slope);
+        if (live) a.out[((long)b * OUT + c) * n + i] = o;
+    }
+}
+
+} // namespace
+
+extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const float* feat, const float* w1t, const float* s1, const float* b1,
+                                 const float* w2t, const float* s2, const float* b2, const float* wft, const float* wmt, const float* sm,
+                                 const float* bm, int B, int n, int K, int D, int OUT, float slope, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xyz && idx && feat && w1t && s1 && b1 && wft && wmt && sm && bm && out, "gdm_lfa_stage_hip: NULL pointer");
+    GDM_CHECK_ARG(!w2t || (s2 && b2), "gdm_lfa_stage_hip: w2t without s2/b2");
+    GDM_CHECK_ARG(K == LK, "gdm_lfa_stage_hip: K=%d, only K=16 is built", K);
+    GDM_CHECK_ARG(D == 32 || D == 64 || D == 128 || D == 256, "gdm_lfa_stage_hip: D=%d not in {32,64,128,256}", D);
+    GDM_CHECK_ARG(OUT >= 1 && OUT <= D, "gdm_lfa_stage_hip: OUT=%d must be in [1, D=%d]", OUT, D);
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1, "gdm_lfa_stage_hip: bad shape");
+    LfaArgs a{xyz, idx, feat, w1t, s1, b1, w2t, s2, b2, wft, wmt, sm, bm, out, n, OUT, slope};
+    hipStream_t s = (hipStream_t)stream;
+    const int P = 256 / D;
+    dim3 grid(gdm_cdiv(n, P), B);
+    if (D == 32) hipLaunchKernelGGL(lfa_stage_kernel<32>, grid, dim3(256), 0, s, a);
+    else if (D == 64) hipLaunchKernelGGL(lfa_stage_kernel<64>, grid, dim3(256), 0, s, a);
+    else if (D == 128) hipLaunchKernelGGL(lfa_stage_kernel<128>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lfa_stage_kernel<256>, grid, dim3(256), 0, s, a);
+    return gdm_launch_status("lfa_stage_kernel");
+}

@@ -397,6 +397,28 @@ def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     return x
 
 
+def lfa_stage(xyz, idx, feat, w1t, s1, b1, w2t, s2, b2, wft, wmt, sm, bm, slope=0.2):
+    """One attentive-pooling stage of RandLA's local feature aggregation in one launch (see include/gdm.h gdm_lfa_stage_hip).
+    xyz f32[B,n,3], idx int[B,n,16], feat f32[B,D/2,n(,1)] -> f32[B,OUT,n].  Inference only."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    feat = _dev(feat, torch.float32, "feat")
+    idx = _idx32(idx, "idx")
+    B, n, K = idx.shape
+    H = feat.shape[1]
+    D, OUT = 2 * H, wmt.shape[1]
+    out = torch.empty((B, OUT, n), dtype=torch.float32, device=feat.device)
+    z = 0
+    check(_lib.lib().gdm_lfa_stage_hip(xyz.data_ptr(), idx.data_ptr(), feat.data_ptr(), w1t.data_ptr(), s1.data_ptr(), b1.data_ptr(),
+                                       w2t.data_ptr() if w2t is not None else z, s2.data_ptr() if w2t is not None else z,
+                                       b2.data_ptr() if w2t is not None else z, wft.data_ptr(), wmt.data_ptr(), sm.data_ptr(),
+                                       bm.data_ptr(), B, n, K, D, OUT, float(slope), out.data_ptr(), _stream()), "gdm_lfa_stage_hip")
+    return out
+
+
+def lfa_supported(d_out, K):
+    return K == 16 and d_out in (32, 64, 128, 256)
+
+
 def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
     """y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]) in one pass for the 64-channel fusion
     levels.  x f32[B,64,m], wt f32[64,64] = W transposed (contiguous), t f32[B,64,n], idx int[B,m(,1)].  Inference only."""

@@ -19,6 +19,9 @@ import torch.nn.functional as F
 from . import ops
 from .layers import folded_bn, fused_eval, rl_conv2d
 
+# GDM_FUSED_LFA=0 keeps the attentive-pooling stages on the separate gather / GEMM / pooling kernels (A/B switch)
+USE_FUSED_LFA = __import__("os").environ.get("GDM_FUSED_LFA", "1") != "0"
+
 
 class AttPooling(nn.Module):
     def __init__(self, d_in, d_out):
@@ -40,7 +43,44 @@ class BuildingBlock(nn.Module):
         self.mlp2 = rl_conv2d(d_out // 2, d_out // 2, bn=True)
         self.att_pooling_2 = AttPooling(d_out, d_out)
 
+    def _fused_weights(self):
+        """Transposed weights + folded BatchNorms of both stages, cached until any parameter changes."""
+        convs = (self.mlp1, self.mlp2, self.att_pooling_1.mlp, self.att_pooling_2.mlp)
+        deps = [m.conv.weight for m in convs] + [self.att_pooling_1.fc.weight, self.att_pooling_2.fc.weight]
+        for m in convs:
+            deps += [m.bn.bn.weight, m.bn.bn.bias, m.bn.bn.running_mean, m.bn.bn.running_var]
+        key = tuple((t._version, t.data_ptr()) for t in deps)
+        cache = self.__dict__.get("_gdm_lfa")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                def wt(conv):
+                    return conv.weight.view(conv.weight.shape[0], -1).t().contiguous()
+                w = dict(w1t=wt(self.mlp1.conv), w2t=wt(self.mlp2.conv), wf1=wt(self.att_pooling_1.fc), wf2=wt(self.att_pooling_2.fc),
+                         wm1=wt(self.att_pooling_1.mlp.conv), wm2=wt(self.att_pooling_2.mlp.conv))
+                w["s1"], w["b1"] = folded_bn(self.mlp1.bn.bn)
+                w["s2"], w["b2"] = folded_bn(self.mlp2.bn.bn)
+                w["sm1"], w["bm1"] = folded_bn(self.att_pooling_1.mlp.bn.bn)
+                w["sm2"], w["bm2"] = folded_bn(self.att_pooling_2.mlp.bn.bn)
+            cache = (key, w)
+            self.__dict__["_gdm_lfa"] = cache
+        return cache[1]
+
+    def _fusable(self, feature, neigh_idx):
+        acts = (self.mlp1, self.mlp2, self.att_pooling_1.mlp, self.att_pooling_2.mlp)
+        return (USE_FUSED_LFA and fused_eval(feature, self) and ops.lfa_supported(2 * feature.shape[1], neigh_idx.shape[-1])
+                and all(isinstance(getattr(m, "activation", None), nn.LeakyReLU) and m.activation.negative_slope == 0.2
+                        and m.conv.bias is None for m in acts))
+
     def forward(self, xyz, feature, neigh_idx):            # feature [B,C,n,1]
+        if self._fusable(feature, neigh_idx):
+            # both attentive-pooling stages as one launch each: nothing of size n*K reaches HBM
+            w = self._fused_weights()
+            B, H, n = feature.shape[0], feature.shape[1], feature.shape[2]
+            agg = ops.lfa_stage(xyz, neigh_idx, feature.reshape(B, H, n), w["w1t"], w["s1"], w["b1"], None, None, None,
+                                w["wf1"], w["wm1"], w["sm1"], w["bm1"])
+            out = ops.lfa_stage(xyz, neigh_idx, agg, w["w1t"], w["s1"], w["b1"], w["w2t"], w["s2"], w["b2"],
+                                w["wf2"], w["wm2"], w["sm2"], w["bm2"])
+            return out.unsqueeze(3)
         f_xyz = ops.rel_pos_enc(xyz, neigh_idx)             # [B,10,n,K]
         f_xyz = self.mlp1(f_xyz)
         f_neighbours = ops.group_gather(feature, neigh_idx)  # [B,C,n,K]

@@ -197,6 +197,21 @@ int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* matc
                             const float* lse_p, const float* lse_n, const float* grad_rows, float* dsim, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * One attentive-pooling stage of RandLA-Net's local feature aggregation in a single launch (inference):
+ * models/RandLA/RandLANet.py:700-718 Building_block.forward = two such stages; :720-727 relative_pos_encoding, :729-738
+ * gather_neighbour, :747-754 Att_pooling.forward.  For every point i with neighbours idx[b,i,0..15]:
+ *   f_xyz  = lrelu(s1 * (W1 . pos_enc(i, k)) + b1)                      (10 -> D/2; pos_enc = [dist, rel(3), tile(3), neighbour(3)])
+ *   f_xyz  = lrelu(s2 * (W2 . f_xyz) + b2)                              only when w2t != NULL (the block's second stage, mlp2)
+ *   f_cat  = [feat[:, idx[b,i,k]] ; f_xyz]                              (D x 16)
+ *   att    = Wf . f_cat ; score = softmax_k(att) ; agg = sum_k f_cat * score
+ *   out[b,:,i] = lrelu(sm * (Wm . agg) + bm)                            (D -> OUT <= D)
+ * xyz f32[B,n,3], idx i32[B,n,16], feat f32[B,D/2,n], out f32[B,OUT,n]; weights TRANSPOSED ([in][out], contiguous):
+ * w1t [10,D/2], w2t [D/2,D/2], wft [D,D], wmt [D,OUT]; s*, b* = eval-mode BatchNorm folded to scale / shift.  D in {32,64,128,256}. */
+int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const float* feat, const float* w1t, const float* s1, const float* b1,
+                      const float* w2t, const float* s2, const float* b2, const float* wft, const float* wmt, const float* sm,
+                      const float* bm, int B, int n, int K, int D, int OUT, float slope, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Pose solve statistics (evaluator.py:85-100 + utils/pvn3d_eval_utils_kpls.py:43-77 best_fit_transform).
  * Per crop, over the points with mask != 0: out[b] = { n, sum A (3), sum B (3), sum A_i B_j (9, row-major) } as f64,
  * A = model_xyz[best_idx] (f32[M,3]), B = scene point.  Scene xyz addressing: element (b, i, c) at

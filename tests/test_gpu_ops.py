@@ -410,3 +410,30 @@ def test_conv1x1_gather_add_act(ops, act):
         ref = torch.where(ref > 0, ref, ref * 0.2)
     got = ops.conv1x1_gather_add_act(x.cuda(), w.t().contiguous().cuda(), t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2).cpu()
     assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("d_out,n", [(32, 100), (64, 257), (128, 64), (256, 33)])
+def test_fused_lfa_stage_equals_unfused_block(ops, d_out, n):
+    """Building_block (RandLANet.py:700-718) as two fused attentive-pooling launches == the gather / GEMM / softmax-pool chain
+    of separate kernels (itself pinned against the reference's golden block outputs)."""
+    from geometric_aware_dense_matching_amd import randla
+    torch.manual_seed(d_out)
+    blk = randla.BuildingBlock(d_out).cuda().eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    B, K = 3, 16
+    xyz = torch.randn(B, n, 3, device="cuda")
+    feat = torch.randn(B, d_out // 2, n, 1, device="cuda")
+    idx = torch.randint(0, n, (B, n, K), device="cuda", dtype=torch.int32)
+    with torch.no_grad():
+        randla.USE_FUSED_LFA = False
+        ref = blk(xyz, feat, idx)
+        randla.USE_FUSED_LFA = True
+        got = blk(xyz, feat, idx)
+    assert got.shape == ref.shape == (B, d_out, n, 1)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
