@@ -11,7 +11,7 @@
 //
 // Thread = (point slot p, channel c): a workgroup of 256 threads owns 256/D points.  Weights come pre-transposed ([in][out]),
 // so the load of W^T[j][c] is contiguous over c; the d x K block is broadcast-read from LDS as 16-byte quads; the softmax over
-// K and the weighted sum are in-thread (att_pool_kernel's arithmetic, same order).  Exact fp32 FMAs; K = 16.
+// K and the weighted sum are in-thread.  fp32 FMAs; K = 16.
 #include "gdm_common.h"
 #include <math.h>
 
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
         float acc[8];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) acc[kk] = 0.f;
+#pragma unroll 8
         for (int q = 0; q < H; ++q) {
             const float w = a.w2t[q * H + j];
             const float4 f0 = *reinterpret_cast<const float4*>(&fx1[p][q][kb]);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
     float att[LK];
 #pragma unroll
     for (int k = 0; k < LK; ++k) att[k] = 0.f;
-#pragma unroll 2
+#pragma unroll 8
     for (int jj = 0; jj < D; ++jj) {
         const float w = a.wft[jj * D + c];
         const float4* fr = reinterpret_cast<const float4*>(&fcat[p][jj][0]);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
         att[8] = fmaf(w, f2.x, att[8]); att[9] = fmaf(w, f2.y, att[9]); att[10] = fmaf(w, f2.z, att[10]); att[11] = fmaf(w, f2.w, att[11]);
         att[12] = fmaf(w, f3.x, att[12]); att[13] = fmaf(w, f3.y, att[13]); att[14] = fmaf(w, f3.z, att[14]); att[15] = fmaf(w, f3.w, att[15]);
     }
-    // 4. softmax over K, feature * score, sum over K (att_pool_kernel's order)
+    // 4. softmax over K, feature * score, sum over K
     {
         float mx = att[0];
 #pragma unroll
@@ -139,12 +140,13 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
         float den = 0.f;
 #pragma unroll
         for (int k = 0; k < LK; ++k) {
-            att[k] = expf(att[k] - mx);
+            att[k] = __expf(att[k] - mx);                  // v_exp_f32 path (arguments <= 0): ~1 ulp, far inside the 1e-4 budget
             den += att[k];
         }
+        const float rden = 1.0f / den;
         float num = 0.f;
 #pragma unroll
-        for (int k = 0; k < LK; ++k) num += fcat[p][c][k] * (att[k] / den);
+        for (int k = 0; k < LK; ++k) num = fmaf(fcat[p][c][k], att[k] * rden, num);
         aggv[p][c] = num;
     }
     __syncthreads();
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
     const int OUT = a.OUT;
     if (c < OUT) {
         float o = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int jj = 0; jj < D; ++jj) o = fmaf(a.wmt[jj * OUT + c], aggv[p][jj], o);
         o = lrelu(fmaf(o, a.sm[c], a.bm[c]), slope);
         if (live) a.out[((long)b * OUT + c) * n + i] = o;
