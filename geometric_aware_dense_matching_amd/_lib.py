@@ -77,6 +77,7 @@ SIGNATURES = {
     "gdm_depth_to_xyz_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gdm_spline_direct_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

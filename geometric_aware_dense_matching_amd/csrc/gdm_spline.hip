@@ -112,7 +112,82 @@ __global__ __launch_bounds__(128) void spline_aggregate_bwd_kernel(const float* 
     }
 }
 
+// Few input channels (the first mesh layer: 9 -> 128): the dense form would write and re-read an [M, 125*C] table (524 MB at
+// M = 8192) for a GEMM with K = 9.  Here the message is formed directly, out_i = mean_e sum_s b_s * (x_j . W[wi_s]) + x_i . W_root + bias:
+// thread = output channel, the CIN inputs of x_j are wave-uniform, W[wi][q][:] rows are contiguous over the output channel.
+template <bool RELU, int CIN_MAX>
+__global__ __launch_bounds__(128) void spline_direct_kernel(const float* __restrict__ x,        // [M, Cin]
+                                                            const float* __restrict__ w,        // [KS^3, Cin, C]
+                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                            const float* __restrict__ attr, const float* __restrict__ root_t,  // [Cin, C]
+                                                            const float* __restrict__ bias, int Cin, int C, int KS, float* __restrict__ out)
+{
+    const int i = blockIdx.x;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int o = threadIdx.x; o < C; o += blockDim.x) {
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int j = src[e];
+            float xj[CIN_MAX];
+#pragma unroll
+            for (int q = 0; q < CIN_MAX; ++q) xj[q] = q < Cin ? x[(long)j * Cin + q] : 0.f;
+            float fr[3];
+            int fl[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = attr[3 * e + d] * (float)(KS - 1);     // open spline, degree 1
+                const float f = floorf(v);
+                fl[d] = (int)f;
+                fr[d] = v - f;
+            }
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                int wi = 0, off = 1;
+                float b = 1.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int kd = (s >> d) & 1;
+                    wi += ((fl[d] + kd) % KS) * off;
+                    off *= KS;
+                    b *= kd ? fr[d] : 1.f - fr[d];
+                }
+                const float* wr = w + (long)wi * Cin * C + o;
+                float dot = 0.f;
+#pragma unroll
+                for (int q = 0; q < CIN_MAX; ++q)
+                    if (q < Cin) dot = fmaf(xj[q], wr[(long)q * C], dot);
+                m += b * dot;
+            }
+            acc += m;
+        }
+        const int deg = e1 - e0;
+        float r = deg > 0 ? acc / (float)deg : 0.f;
+        if (root_t) {
+            float dot = 0.f;
+            for (int q = 0; q < Cin; ++q) dot = fmaf(x[(long)i * Cin + q], root_t[(long)q * C + o], dot);
+            r += dot;
+        }
+        if (bias) r += bias[o];
+        if (RELU) r = fmaxf(r, 0.f);
+        out[(long)i * C + o] = r;
+    }
+}
+
 } // namespace
+
+extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                     const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                                     float* out, void* stream)
+{
+    GDM_CHECK_ARG(x && weight && rowptr && src && attr && out, "gdm_spline_direct_hip: NULL pointer");
+    GDM_CHECK_ARG(M >= 1 && C >= 1 && kernel_size >= 2 && Cin >= 1 && Cin <= 16, "gdm_spline_direct_hip: bad shape M=%d Cin=%d (<= 16) C=%d ks=%d", M, Cin, C, kernel_size);
+    if (relu)
+        hipLaunchKernelGGL((spline_direct_kernel<true, 16>), dim3(M), dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t, bias, Cin, C, kernel_size, out);
+    else
+        hipLaunchKernelGGL((spline_direct_kernel<false, 16>), dim3(M), dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t, bias, Cin, C, kernel_size, out);
+    return gdm_launch_status("spline_direct_kernel");
+}
 
 extern "C" int gdm_spline_aggregate_hip(const float* xw, const int32_t* rowptr, const int32_t* src, const float* attr,
                                         const float* root, const float* bias, int M, int C, int kernel_size, int relu,

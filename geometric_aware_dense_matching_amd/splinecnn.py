@@ -81,6 +81,20 @@ class SplineConv(nn.Module):
     def forward(self, x, rowptr, src, attr, relu=False):
         M = x.shape[0]
         nk = KERNEL_SIZE ** 3
+        if self.cin <= 16 and x.is_cuda and not torch.is_grad_enabled():
+            # few input channels (first layer, 9 -> 128): messages formed directly, no [M, 125*out] table (524 MB at M = 8192)
+            w = self.lin.weight
+            key = (w._version, w.data_ptr())
+            cache = self.__dict__.get("_gdm_root_t")
+            if cache is None or cache[0] != key:
+                cache = (key, w.detach().t().contiguous())
+                self.__dict__["_gdm_root_t"] = cache
+            out = torch.empty((M, self.cout), dtype=torch.float32, device=x.device)
+            xc = x.contiguous()
+            check(_lib.lib().gdm_spline_direct_hip(xc.data_ptr(), self.weight.data_ptr(), rowptr.data_ptr(), src.data_ptr(), attr.data_ptr(),
+                                                   cache[1].data_ptr(), self.bias.data_ptr(), M, self.cin, self.cout, KERNEL_SIZE, int(relu),
+                                                   out.data_ptr(), ops._stream()), "gdm_spline_direct_hip")
+            return out
         if (USE_MFMA_GEMM and not torch.is_grad_enabled() and x.is_cuda
                 and ops.gemm_supported(self.cin, nk * self.cout, M)):
             # dense part on the split-bf16 MFMA GEMM, written node-major ([M, 125*out]) as the aggregation kernel reads it

@@ -165,6 +165,12 @@ int gdm_spline_aggregate_hip(const float* xw, const int32_t* rowptr, const int32
 /* grad_xw[src, wi_s, :] += b_s * grad_out[target, :] / deg(target); grad_xw zeroed by the caller. */
 int gdm_spline_aggregate_bwd_hip(const float* grad_out, const int32_t* rowptr, const int32_t* src, const float* attr,
                                  int M, int C, int kernel_size, float* grad_xw, void* stream);
+/* The same layer for few input channels (Cin <= 16; the first mesh layer, 9 -> 128) without the [M, 125*C] table:
+ * out_i = mean_e sum_s b_s (x_j . W[wi_s]) + x_i . W_root + bias; x f32[M,Cin], weight f32[ks^3,Cin,C] (SplineConv.weight as stored),
+ * root_t f32[Cin,C] (lin.weight transposed, may be NULL), bias f32[C] (may be NULL). */
+int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                          const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                          float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).

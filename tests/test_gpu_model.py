@@ -413,3 +413,24 @@ def test_graphed_pipeline_equals_eager(golden_model):
     assert torch.equal(got["valid"], valid)
     if bool(valid.all()):
         assert torch.allclose(got["RT"], RT, atol=1e-3)
+
+
+def test_spline_direct_first_layer_equals_dense_form():
+    """SplineConv with few input channels: direct message kernel == dense GEMM + CSR aggregation (the training-path form)."""
+    from geometric_aware_dense_matching_amd import splinecnn
+    torch.manual_seed(3)
+    M = 1500
+    pos = torch.rand(M, 3, device="cuda")
+    ei, ea = splinecnn.build_mesh_graph(pos, k=4)
+    order = torch.argsort(ei[1], stable=True)
+    rowptr = torch.zeros(M + 1, dtype=torch.int32, device="cuda")
+    rowptr[1:] = torch.cumsum(torch.bincount(ei[1][order], minlength=M), 0).to(torch.int32)
+    src, attr = ei[0][order].to(torch.int32).contiguous(), ea[order].contiguous()
+    conv = splinecnn.SplineConv(9, 128).cuda()
+    conv.bias.data.normal_(0, 0.1)
+    x = torch.randn(M, 9, device="cuda")
+    with torch.enable_grad():
+        dense = conv(x, rowptr, src, attr, relu=True).detach()
+    with torch.no_grad():
+        direct = conv(x, rowptr, src, attr, relu=True)
+    assert (dense - direct).abs().max().item() < 1e-5 * max(1.0, dense.abs().max().item())
