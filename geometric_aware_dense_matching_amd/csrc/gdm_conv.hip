@@ -62,20 +62,21 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
 {
     __shared__ float t[128][65];
     const int b = blockIdx.z, chunk = blockIdx.y;
-    const int nchunk = C / 128;
+    const int nchunk = (C + 127) / 128;
+    const int cvalid = min(128, C - chunk * 128);          // a trailing partial chunk: the missing channels' planes stay zero
     const int hw = H * W;
     const long plane = (long)(H + 2) * (W + 2);
     const int p0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = min(p0 + lane, hw - 1);
     const float* xb = x + ((long)b * C + chunk * 128) * hw;
-    for (int c = w; c < 128; c += 4) t[c][lane] = xb[(long)c * hw + p];
+    for (int c = w; c < cvalid; c += 4) t[c][lane] = xb[(long)c * hw + p];
     __syncthreads();
     const int pp = p0 + lane;
     if (pp >= hw) return;
     const int y = pp / W, xx = pp - y * W;
     unsigned char* o = out + (((long)(b * nchunk + chunk) * 32) * plane + (long)(y + 1) * (W + 2) + xx + 1) * 16;
-    for (int q = w; q < 16; q += 4) {                    // consecutive lanes = consecutive pixels: 1-KiB contiguous stores
+    for (int q = w; q * 8 < cvalid; q += 4) {            // consecutive lanes = consecutive pixels: 1-KiB contiguous stores
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = t[q * 8 + j][lane];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
 // up to 128, rows co >= Cout are zero (a workgroup always stages 128 rows)
 __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, unsigned char* __restrict__ out)
 {
-    const int nchunk = Cin / 128;
+    const int nchunk = (Cin + 127) / 128;
     const int CoutP = (Cout + 127) & ~127;
     const long item = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 16 groups of 8 channels)
     const long rows = (long)taps * nchunk * CoutP;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
     const int chunk = tc % nchunk, tap = tc / nchunk;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = co < Cout ? w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap] : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = (co < Cout && chunk * 128 + ch * 8 + j < Cin) ? w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap] : 0.f;
     unsigned hi[4], lo[4];
     split8(v, hi, lo);
     unsigned char* r = out + row * ROWB;
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
 
 __device__ __forceinline__ int swz(int col, int ch) { return col * ROWB + (((ch & 16) | ((ch ^ col) & 15)) << 4); }
 
-template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false>   // TAPS 1 = 1x1 convolution / plain GEMM (centre tap only)
+// TAPS 1 = 1x1 convolution / plain GEMM (centre tap only); NKS = k-steps of 16 channels per chunk (4: a single 64-channel chunk)
+template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, h = lane >> 5;
-    const int nchunk = Cin / 128;
+    const int nchunk = (Cin + 127) / 128;
     const int npanel = TAPS * nchunk;
     const int hw = H * W;
     const long ptot = (long)B * hw;
@@ -179,13 +181,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 #ifndef GDM_CONV_LATE
 #define GDM_CONV_LATE 2
 #endif
-    constexpr int LATE = GDM_CONV_LATE;                                         // k-steps whose reload is deferred to the next iteration's top
+    constexpr int LATE = NKS == 8 ? GDM_CONV_LATE : 1;                                         // k-steps whose reload is deferred to the next iteration's top
     stage_load(0);
     stage_store(0);
     {
         const unsigned char* r0 = a_row(0);
 #pragma unroll
-        for (int ss = 0; ss < 8 - LATE; ++ss) load_a(r0, ss);
+        for (int ss = 0; ss < NKS - LATE; ++ss) load_a(r0, ss);
     }
     for (int it = 0; it < npanel; ++it) {
         if (!(GDM_CONV_EXP & 1) || it == 0) __syncthreads();       // panel `it` is in LDS; panel it-1's readers are done
@@ -202,10 +204,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
             fl[j] = *reinterpret_cast<const u32x4*>(base + swz(j * 32 + lr, 16 + h));
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 2 * NKS; ++u) {
             const int s = u >> 1, pr = u & 1;
             u32x4 nh[2], nl[2];
-            if (u < 15) {
+            if (u < 2 * NKS - 1) {
                 const int sn = (u + 1) >> 1, pn = (u + 1) & 1;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -221,17 +223,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
             for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
-            if (pr == 1 && s < 8 - LATE && !(GDM_CONV_EXP & 2)) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
+            if (pr == 1 && s < NKS - LATE && !(GDM_CONV_EXP & 2)) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
             if (u == 0) {
                 // issued BEHIND the first MFMAs: the wait hipcc puts in front of them for the loop-carried operand registers
                 // is a vmcnt(0), and must not find this iteration's loads already in flight
                 if (more && !(GDM_CONV_EXP & 1)) stage_load(it + 1);
                 if (!(GDM_CONV_EXP & 2) || it == 0) {
 #pragma unroll
-                    for (int ss = 8 - LATE; ss < 8; ++ss) load_a(rcur, ss);
+                    for (int ss = NKS - LATE; ss < NKS; ++ss) load_a(rcur, ss);
                 }
             }
-            if (u < 15) {
+            if (u < 2 * NKS - 1) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     fh[j] = nh[j];
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u < 15 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (u < 2 * NKS - 1 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -297,10 +299,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 
 } // namespace
 
+static bool cin_ok(int Cin) { return Cin == 64 || (Cin >= 128 && Cin % 128 == 0); }
+
 extern "C" size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W)
 {
-    if (B < 1 || Cin < 128 || Cin % 128 || H < 1 || W < 1) return 0;
-    return (size_t)B * (H + 2) * (W + 2) * (Cin / 128) * ROWB;
+    if (B < 1 || !cin_ok(Cin) || H < 1 || W < 1) return 0;
+    return (size_t)B * (H + 2) * (W + 2) * ((Cin + 127) / 128) * ROWB;
 }
 
 extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
@@ -311,15 +315,15 @@ extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
 
 extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
 {
-    if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
-    return (size_t)(Cin / 128) * ((Cout + 127) & ~127) * ROWB;
+    if (Cout < 1 || !cin_ok(Cin)) return 0;
+    return (size_t)((Cin + 127) / 128) * ((Cout + 127) & ~127) * ROWB;
 }
 
 static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who)
 {
     GDM_CHECK_ARG(w && wpk, "%s: NULL pointer", who);
-    GDM_CHECK_ARG(Cout >= 1 && Cin >= 128 && Cin % 128 == 0, "%s: Cout=%d Cin=%d (Cin %% 128 == 0)", who, Cout, Cin);
-    const long items = (long)taps * (Cin / 128) * ((Cout + 127) & ~127) * 16;
+    GDM_CHECK_ARG(Cout >= 1 && cin_ok(Cin) && (taps == 1 || Cin % 128 == 0), "%s: Cout=%d Cin=%d (a multiple of 128; 64 for the 1x1 form)", who, Cout, Cin);
+    const long items = (long)taps * ((Cin + 127) / 128) * ((Cout + 127) & ~127) * 16;
     hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk);
     return gdm_launch_status("conv_pack_w_kernel");
 }
@@ -338,8 +342,8 @@ extern "C" int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, vo
 extern "C" int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, int W, void* xpk, void* stream)
 {
     GDM_CHECK_ARG(x && xpk, "gdm_conv3x3_pack_act_hip: NULL pointer");
-    GDM_CHECK_ARG(B >= 1 && B <= 65535 && Cin >= 128 && Cin % 128 == 0 && H >= 1 && W >= 1, "gdm_conv3x3_pack_act_hip: bad shape");
-    dim3 grid(gdm_cdiv((long)H * W, 64), Cin / 128, B);
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && cin_ok(Cin) && H >= 1 && W >= 1, "gdm_conv3x3_pack_act_hip: bad shape (Cin=%d: a multiple of 128, or 64)", Cin);
+    dim3 grid(gdm_cdiv((long)H * W, 64), (Cin + 127) / 128, B);
     hipLaunchKernelGGL(conv_pack_act_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, H, W, (unsigned char*)xpk);
     return gdm_launch_status("conv_pack_act_kernel");
 }
@@ -375,7 +379,8 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
                                       int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream)
 {
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
-    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128)", Cin, Cout);
+    GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
+    GDM_CHECK_ARG(Cin != 64 || !pixel_major, "gdm_conv1x1_packed_hip: Cin=64 is built for the NCHW output only");
     GDM_CHECK_ARG(W % 32 == 0 && H >= 1, "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32", W);
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
@@ -387,7 +392,15 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
         attr = true;
+    }
+    if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
+#define C1H(A) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, false, 1, false, 4>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+        if (act == 0) C1H(0); else C1H(1);
+#undef C1H
+        return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
 #define C1(A, P) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, false, 1, P>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
     if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }

@@ -507,9 +507,9 @@ def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None)
 
 
 def gemm_supported(cin, cout, npix):
-    """K in whole 128-channel chunks; output channels are padded to 128 inside the kernel (zero weight rows, masked stores), which
+    """K in whole 128-channel chunks (or exactly 64); output channels are padded to 128 inside the kernel (zero weight rows, masked stores), which
     pays once the padding wastes at most a third of the MFMA work."""
-    return cin % 128 == 0 and (cout % 128 == 0 or cout >= 192) and npix % 32 == 0
+    return (cin % 128 == 0 or cin == 64) and (cout % 128 == 0 or cout >= 192) and npix % 32 == 0
 
 
 def gemm_pack_weight(weight2d):

@@ -377,7 +377,7 @@ def test_final_stage_and_psp_pools(ops):
         assert torch.allclose(o.cpu(), torch.nn.functional.adaptive_avg_pool2d(f2, s_), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,n", [(2, 128, 256, 1024), (1, 1024, 2304, 1024), (1, 128, 16000, 8192), (2, 256, 576, 4096), (1, 128, 200, 64)])
+@pytest.mark.parametrize("B,Cin,Cout,n", [(2, 128, 256, 1024), (1, 1024, 2304, 1024), (1, 128, 16000, 8192), (2, 256, 576, 4096), (1, 128, 200, 64), (2, 64, 576, 4096), (1, 64, 128, 96)])
 def test_gemm_bf16x3(ops, B, Cin, Cout, n):
     rs = np.random.RandomState(Cin + n)
     x = torch.from_numpy(rs.randn(B, Cin, n).astype(np.float32))
@@ -387,8 +387,9 @@ def test_gemm_bf16x3(ops, B, Cin, Cout, n):
     got = ops.gemm_bf16x3(x.cuda(), wpk, Cout).cpu()
     tol = 2e-5 * max(1.0, ref.abs().max().item())
     assert (got.double() - ref).abs().max().item() < tol
-    got_pm = ops.gemm_bf16x3(x.cuda(), wpk, Cout, pixel_major=True).cpu().view(B, n, Cout).transpose(1, 2)
-    assert (got_pm.double() - ref).abs().max().item() < tol
+    if Cin != 64:        # the 64-channel (half-chunk) form is built for NCHW output only
+        got_pm = ops.gemm_bf16x3(x.cuda(), wpk, Cout, pixel_major=True).cpu().view(B, n, Cout).transpose(1, 2)
+        assert (got_pm.double() - ref).abs().max().item() < tol
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
