@@ -106,36 +106,46 @@ __device__ __forceinline__ void knn_group_body(const KnnJobDev& job, int local, 
         __syncthreads();
         const int npt = (S - t + ntiles - 1) / ntiles;               // valid slots in this tile
         const int steps = (npt + G - 1) / G;
-        for (int s = 0; s < steps; ++s) {
-            const float4 v = tile[s * G + g];
-            const float d = dist2_ref(qx, qy, qz, v.x, v.y, v.z);
-            const int di = __float_as_int(v.w);
-            bool pass = d < worst || (d == worst && di < worst_i);
-            unsigned long long bal = __ballot(pass);
-            while (bal) {                            // wave-uniform loop
-                const unsigned long long m = (bal >> gbase) & gmask;
-                const bool act = m != 0ull;          // group-uniform
-                const int src = act ? __builtin_ctzll(m) : 0;
-                const float cd = __shfl(d, gbase + src, 64);
-                const int ci = __shfl(di, gbase + src, 64);
-                const bool before = ld < cd || (ld == cd && li < ci);
-                const unsigned long long le = (__ballot(before) >> gbase) & gmask & kmask;
-                const int pos = __builtin_popcountll(le);        // entries that stay in front of the candidate
-                const float ud = __shfl_up(ld, 1, G);
-                const int ui = __shfl_up(li, 1, G);
-                if (act) {
-                    if (g > pos) {
-                        ld = ud;
-                        li = ui;
-                    } else if (g == pos) {
-                        ld = cd;
-                        li = ci;
+        // four steps' candidates are fetched and their distances formed before any of them is considered: the read and the
+        // dependent arithmetic chain of a step (~150 cycles of latency) would otherwise sit in front of every ballot
+        for (int s = 0; s < steps; s += 4) {
+            float4 v4[4];
+            float d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = tile[min(s + u, KNN_TILE / G - 1) * G + g];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d4[u] = dist2_ref(qx, qy, qz, v4[u].x, v4[u].y, v4[u].z);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = d4[u];
+                const int di = __float_as_int(v4[u].w);
+                bool pass = (s + u < steps) && (d < worst || (d == worst && di < worst_i));
+                unsigned long long bal = __ballot(pass);
+                while (bal) {                            // wave-uniform loop
+                    const unsigned long long m = (bal >> gbase) & gmask;
+                    const bool act = m != 0ull;          // group-uniform
+                    const int src = act ? __builtin_ctzll(m) : 0;
+                    const float cd = __shfl(d, gbase + src, 64);
+                    const int ci = __shfl(di, gbase + src, 64);
+                    const float ud = __shfl_up(ld, 1, G);
+                    const int ui = __shfl_up(li, 1, G);
+                    const bool before = ld < cd || (ld == cd && li < ci);
+                    const unsigned long long le = (__ballot(before) >> gbase) & gmask & kmask;
+                    const int pos = __builtin_popcountll(le);        // entries that stay in front of the candidate
+                    if (act) {
+                        if (g > pos) {
+                            ld = ud;
+                            li = ui;
+                        } else if (g == pos) {
+                            ld = cd;
+                            li = ci;
+                        }
                     }
+                    worst = __shfl(ld, gbase + K - 1, 64);
+                    worst_i = __shfl(li, gbase + K - 1, 64);
+                    pass = pass && !(act && g == src) && (d < worst || (d == worst && di < worst_i));
+                    bal = __ballot(pass);
                 }
-                worst = __shfl(ld, gbase + K - 1, 64);
-                worst_i = __shfl(li, gbase + K - 1, 64);
-                pass = pass && !(act && g == src) && (d < worst || (d == worst && di < worst_i));
-                bal = __ballot(pass);
             }
         }
     }
