@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
     const int oy = oy_t + ty, ox0 = ox_t + tx * 4;
     if (oy >= OH || ox0 >= OW) return;
     int cx0[6];
-    float clx[6];
+    float clx[6], chx[6];
     bool cok[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
         const int x0 = min((int)sx, W - 1);
         cx0[j] = x0 - xs0;
         clx[j] = sx - (float)x0;
+        chx[j] = 1.f - clx[j];
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -256,9 +257,13 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
             for (int j = 0; j < 4; ++j) {
                 const int c = j + dx + 1;
                 if (cok[c] && ox0 + j < OW) {
-                    const float lx = clx[c], hx = 1.f - lx;
+                    // explicit FMAs (the build runs with -ffp-contract=off): 6 VALU ops per tap and output instead of 10;
+                    // the kernel is VALU-bound (9 taps x 4 corners per output)
+                    const float lx = clx[c], hx = chx[c];
                     const int xo = cx0[c];
-                    acc[j] += hy * (hx * r0[xo] + lx * r0[xo + 1]) + ly * (hx * r1[xo] + lx * r1[xo + 1]);
+                    const float top = fmaf(lx, r0[xo + 1], hx * r0[xo]);
+                    const float bot = fmaf(lx, r1[xo + 1], hx * r1[xo]);
+                    acc[j] = fmaf(ly, bot, fmaf(hy, top, acc[j]));
                 }
             }
         }
