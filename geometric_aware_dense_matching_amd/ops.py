@@ -557,7 +557,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         go = go.contiguous()
         B, C, OH, OW = go.shape
         H, W = ctx.hw
-        g = torch.zeros((B, C, H, W), dtype=torch.float32, device=go.device)
+        g = torch.empty((B, C, H, W), dtype=torch.float32, device=go.device)
         check(_lib.lib().gdm_upsample_bilinear_bwd_hip(go.data_ptr(), B * C, H, W, OH, OW, g.data_ptr(), _stream()),
               "gdm_upsample_bilinear_bwd_hip")
         return g, None, None

@@ -174,8 +174,8 @@ int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* ro
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).
- * in f32[planes,H,W] -> out f32[planes,OH,OW]; planes = B*C.  Backward adds into grad_in
- * (zeroed by the caller).                                                               */
+ * in f32[planes,H,W] -> out f32[planes,OH,OW]; planes = B*C.  Backward writes every element of grad_in
+ * (gather form: no atomics, deterministic).                                             */
 int gdm_upsample_bilinear_hip(const float* in, long planes, int H, int W, int OH, int OW, float* out, void* stream);
 int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes, int H, int W, int OH, int OW, float* grad_in, void* stream);
 
