@@ -563,6 +563,32 @@ class _UpsampleBilinear(torch.autograd.Function):
         return g, None, None
 
 
+class _PReLU1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().gdm_prelu1_hip(x.data_ptr(), slope.data_ptr(), x.numel(), y.data_ptr(), _stream()), "gdm_prelu1_hip")
+        ctx.save_for_backward(x, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, slope = ctx.saved_tensors
+        go = go.contiguous()
+        gx = torch.empty_like(x)
+        gs = torch.zeros_like(slope)
+        check(_lib.lib().gdm_prelu1_bwd_hip(x.data_ptr(), go.data_ptr(), slope.data_ptr(), x.numel(), gx.data_ptr(), gs.data_ptr(), _stream()),
+              "gdm_prelu1_bwd_hip")
+        return gx, gs
+
+
+def prelu1(x, slope):
+    """Single-parameter PReLU with a streaming HIP backward (training path of PSPUpsample). x f32 cuda, numel % 4 == 0."""
+    x = _dev(x, torch.float32, "x")
+    return _PReLU1.apply(x, slope)
+
+
 def upsample_bilinear(x, size):
     """x f32[B,C,H,W] -> f32[B,C,OH,OW], bilinear, align_corners=True (pspnet.py:26-29,38)."""
     return _UpsampleBilinear.apply(x, int(size[0]), int(size[1]))

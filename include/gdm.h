@@ -231,6 +231,11 @@ int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stri
  * quaternion (largest eigenvector of a symmetric 4x4, cyclic Jacobi, f64) -- the same R as SVD + reflection fix. */
 int gdm_kabsch_solve_hip(const double* stats, int B, int min_points, float* RT, uint8_t* valid, void* stream);
 
+/* Single-slope PReLU (models/cnn/pspnet.py:41) and its backward, for training: y = x > 0 ? x : a x; grad_x = x > 0 ? go : a go;
+ * grad_slope[0] += sum over x <= 0 of x * go (zeroed by the caller).  slope is a DEVICE pointer to the one parameter; n % 4 == 0. */
+int gdm_prelu1_hip(const float* x, const float* slope, long n, float* y, void* stream);
+int gdm_prelu1_bwd_hip(const float* x, const float* grad_out, const float* slope, long n, float* grad_x, float* grad_slope, void* stream);
+
 /* Inference-mode BatchNorm + activation (+ residual branch with its own folded BatchNorm) in one pass:
  * y = act(x*scale[c] + shift[c] (+ res*res_scale[c] + res_shift[c])), c = plane % C; x,res,y f32[planes, inner],
  * inner % 4 == 0; res / res_scale / res_shift may be NULL (res_scale NULL = plain residual add).

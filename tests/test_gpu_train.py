@@ -101,3 +101,20 @@ def test_test_entry_point_runs():
                                               "--synthetic-items 4".split())
     res = train_lm.test(args)
     assert len(res) == 2 and res[0]["best_idx"].shape == (2, 1024) and int(res[0]["best_idx"].max()) < 512
+
+
+def test_prelu1_forward_backward_equals_torch():
+    from geometric_aware_dense_matching_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(3, 5, 16, 12, device="cuda", requires_grad=True)
+    a = torch.nn.Parameter(torch.tensor([0.25], device="cuda"))
+    w = torch.randn_like(x)
+    y = ops.prelu1(x, a)
+    (y * w).sum().backward()
+    gx, ga = x.grad.clone(), a.grad.clone()
+    x.grad = None; a.grad = None
+    yr = torch.nn.functional.prelu(x, a)
+    (yr * w).sum().backward()
+    assert torch.equal(y, yr)
+    assert torch.equal(gx, x.grad)
+    assert torch.allclose(ga, a.grad, rtol=1e-5, atol=1e-5)
