@@ -247,6 +247,51 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_kernel(const float* __re
     }
 }
 
+// Transpose of the 9-tap gather, for training: gz[b, tap*Cout+co, y, x] = sum over the output pixels (oy, ox) whose tap-shifted
+// sample (oy+dy, ox+dx) reads low-resolution pixel (y, x), of wy * wx * go[b, co, oy, ox].  Gather form (one thread per element
+// of gz, the forward's own (y0, y1, ly) arithmetic), no atomics.
+__global__ __launch_bounds__(256) void upconv3x3_gather_bwd_kernel(const float* __restrict__ go, int Cout, int H, int W, int OH, int OW,
+                                                                   float rh, float rw, float* __restrict__ gz)
+{
+    const long plane = blockIdx.y;                       // (b, tap, co)
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= H * W) return;
+    const int co = (int)(plane % Cout);
+    const int tap = (int)((plane / Cout) % 9);
+    const long b = plane / (9L * Cout);
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int y = e / W, x = e - y * W;
+    int Y_lo, Y_hi, X_lo, X_hi;
+    src_range(y, H, OH, rh, Y_lo, Y_hi);
+    src_range(x, W, OW, rw, X_lo, X_hi);
+    // sample position Y = oy + dy must itself lie in the image (the forward skips taps that fall outside), and so must oy
+    Y_lo = max(Y_lo, max(0, dy));
+    Y_hi = min(Y_hi, OH - 1 + min(0, dy));
+    X_lo = max(X_lo, max(0, dx));
+    X_hi = min(X_hi, OW - 1 + min(0, dx));
+    const float* gp = go + (b * Cout + co) * (long)OH * OW;
+    float acc = 0.f;
+    for (int Y = Y_lo; Y <= Y_hi; ++Y) {
+        const float sy = rh * (float)Y;
+        const int y0 = min((int)sy, H - 1);
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly = sy - (float)y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int X = X_lo; X <= X_hi; ++X) {
+            const float sx = rw * (float)X;
+            const int x0 = min((int)sx, W - 1);
+            const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx = sx - (float)x0;
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            row = fmaf(wx, gp[(long)(Y - dy) * OW + (X - dx)], row);
+        }
+        acc = fmaf(wy, row, acc);
+    }
+    gz[plane * (long)H * W + e] = acc;
+}
+
 // LDS-tiled form of upconv3x3_gather for scale factors <= ~0.5 (the x2 upsampling of PSPUpsample): a workgroup
 // owns a 64x16 output tile of one (b, co); the source patch it needs from each of the 9 tap planes
 // (<= 12 x 36 floats for rh, rw <= 0.51) is staged once in LDS with coalesced row reads, then every thread
@@ -635,6 +680,17 @@ extern "C" int gdm_upconv3x3_gather_hip(const float* z, const float* scale, cons
     const int quads = ((OW + 3) / 4) * OH;
     dim3 grid(gdm_cdiv(quads, 256), B * Cout);
     return gdm_launch_status("upconv3x3_gather_kernel");
+}
+
+extern "C" int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Cout, int H, int W, int OH, int OW, float* grad_z, void* stream)
+{
+    GDM_CHECK_ARG(grad_out && grad_z, "gdm_upconv3x3_gather_bwd_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cout >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && (long)B * 9 * Cout <= 65535,
+                  "gdm_upconv3x3_gather_bwd_hip: bad shape B=%d Cout=%d (B*9*Cout <= 65535)", B, Cout);
+    dim3 grid(gdm_cdiv((long)H * W, 256), (unsigned)(B * 9 * Cout));
+    hipLaunchKernelGGL(upconv3x3_gather_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad_out, Cout, H, W, OH, OW,
+                       scale_ac(H, OH), scale_ac(W, OW), grad_z);
+    return gdm_launch_status("upconv3x3_gather_bwd_kernel");
 }
 
 extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,

@@ -370,6 +370,43 @@ def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
     return out
 
 
+class _UpconvGather(torch.autograd.Function):
+    """out = 9-tap bilinear gather of z (+ bias[co]); differentiable in z and bias (training form of PSPUpsample)."""
+
+    @staticmethod
+    def forward(ctx, z, bias, cout, OH, OW):
+        z = z.contiguous()
+        B, c9, H, W = z.shape
+        ones = torch.ones(cout, dtype=torch.float32, device=z.device)
+        shift = bias.detach().contiguous() if bias is not None else torch.zeros(cout, dtype=torch.float32, device=z.device)
+        out = torch.empty((B, cout, OH, OW), dtype=torch.float32, device=z.device)
+        check(_lib.lib().gdm_upconv3x3_gather_hip(z.data_ptr(), ones.data_ptr(), shift.data_ptr(), B, cout, H, W, OH, OW, ACT_NONE, 0.0,
+                                                  out.data_ptr(), _stream()), "gdm_upconv3x3_gather_hip")
+        ctx.shape = (B, cout, H, W, OH, OW)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        B, cout, H, W, OH, OW = ctx.shape
+        go = go.contiguous()
+        gz = torch.empty((B, 9 * cout, H, W), dtype=torch.float32, device=go.device)
+        check(_lib.lib().gdm_upconv3x3_gather_bwd_hip(go.data_ptr(), B, cout, H, W, OH, OW, gz.data_ptr(), _stream()),
+              "gdm_upconv3x3_gather_bwd_hip")
+        return gz, (go.sum(dim=(0, 2, 3)) if ctx.has_bias else None), None, None, None
+
+
+def upconv3x3_gather_train(z, bias, cout, out_size):
+    """Differentiable form of upconv3x3_gather without the folded BN / activation: z f32[B,9*cout,H,W] -> f32[B,cout,OH,OW] (+ bias)."""
+    z = _dev(z, torch.float32, "z")
+    assert z.shape[1] == 9 * cout
+    return _UpconvGather.apply(z, bias, cout, int(out_size[0]), int(out_size[1]))
+
+
+def upconv_train_supported(B, cout):
+    return B * 9 * cout <= 65535
+
+
 def psp_combine(g, ys, bias):
     """out = relu(g + bias + sum_k bilinear_up(ys[k])); g f32[B,C,H,W], ys four f32[B,C,s,s].  Inference only, in place on g."""
     g = _dev(g, torch.float32, "g")

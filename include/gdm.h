@@ -251,6 +251,9 @@ int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, c
  * activation (0 none, 1 ReLU, 2 leaky/PReLU slope) -> out f32[B, Cout, OH, OW].                              */
 int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
                              int OH, int OW, int act, float slope, float* out, void* stream);
+/* Its transpose for training (scale = 1, act = none): grad_z f32[B,9*Cout,H,W] from grad_out f32[B,Cout,OH,OW]; every element of
+ * grad_z is written (gather form, no atomics).  B*9*Cout <= 65535. */
+int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Cout, int H, int W, int OH, int OW, float* grad_z, void* stream);
 
 /* Pyramid-pooling bottleneck tail (pspnet.py:24-31) after splitting the 1x1 convolution over the concat:
  * out = relu(g + bias[c] + sum_k bilinear_align_corners(y_k)), g f32[B,C,H,W] = W_f . feats, y_k f32[B,C,s_k,s_k] = W_k . prior_k. */
