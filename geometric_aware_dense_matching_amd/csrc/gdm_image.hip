@@ -59,6 +59,16 @@ __device__ __forceinline__ void src_range(int i, int n_in, int n_out, float r, i
     hi = min(n_out - 1, (int)ceilf((float)(i + 1) / r) + 1);
 }
 
+// interpolation weight with which output index o reads input index i (the forward's arithmetic)
+__device__ __forceinline__ float tap_weight(int o, int i, int n_in, float r)
+{
+    const float sp = r * (float)o;
+    const int i0 = min((int)sp, n_in - 1);
+    const int i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    const float l = sp - (float)i0;
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ go, int H, int W, int OH, int OW,
                                                                     float rh, float rw, float* __restrict__ gin)
 {
@@ -71,23 +81,30 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     src_range(x, W, OW, rw, ox_lo, ox_hi);
     const float* gp = go + plane * (long)OH * OW;
     float acc = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-        const float sy = rh * (float)oy;
-        const int y0 = (int)sy;
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
-        const float ly = sy - (float)y0;
-        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            const float sx = rw * (float)ox;
-            const int x0 = (int)sx;
-            const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
-            const float lx = sx - (float)x0;
-            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-            row = fmaf(wx, gp[(long)oy * OW + ox], row);
+    if (oy_hi - oy_lo < 10 && ox_hi - ox_lo < 10) {      // the x2 case: <= 10 candidates per axis, weights formed once per axis
+        float wxs[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) wxs[i] = ox_lo + i <= ox_hi ? tap_weight(ox_lo + i, x, W, rw) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int oy = oy_lo + j;
+            const float wy = oy <= oy_hi ? tap_weight(oy, y, H, rh) : 0.f;
+            if (wy != 0.f) {
+                float row = 0.f;
+#pragma unroll
+                for (int i = 0; i < 10; ++i)
+                    if (wxs[i] != 0.f) row = fmaf(wxs[i], gp[(long)oy * OW + ox_lo + i], row);
+                acc = fmaf(wy, row, acc);
+            }
         }
-        acc = fmaf(wy, row, acc);
+    } else {
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const float wy = tap_weight(oy, y, H, rh);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) row = fmaf(tap_weight(ox, x, W, rw), gp[(long)oy * OW + ox], row);
+            acc = fmaf(wy, row, acc);
+        }
     }
     gin[plane * (long)H * W + e] = acc;
 }
@@ -271,23 +288,30 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_bwd_kernel(const float* 
     X_hi = min(X_hi, OW - 1 + min(0, dx));
     const float* gp = go + (b * Cout + co) * (long)OH * OW;
     float acc = 0.f;
-    for (int Y = Y_lo; Y <= Y_hi; ++Y) {
-        const float sy = rh * (float)Y;
-        const int y0 = min((int)sy, H - 1);
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
-        const float ly = sy - (float)y0;
-        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int X = X_lo; X <= X_hi; ++X) {
-            const float sx = rw * (float)X;
-            const int x0 = min((int)sx, W - 1);
-            const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
-            const float lx = sx - (float)x0;
-            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-            row = fmaf(wx, gp[(long)(Y - dy) * OW + (X - dx)], row);
+    if (Y_hi - Y_lo < 10 && X_hi - X_lo < 10) {
+        float wxs[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) wxs[i] = X_lo + i <= X_hi ? tap_weight(X_lo + i, x, W, rw) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int Y = Y_lo + j;
+            const float wy = Y <= Y_hi ? tap_weight(Y, y, H, rh) : 0.f;
+            if (wy != 0.f) {
+                float row = 0.f;
+#pragma unroll
+                for (int i = 0; i < 10; ++i)
+                    if (wxs[i] != 0.f) row = fmaf(wxs[i], gp[(long)(Y - dy) * OW + (X_lo + i - dx)], row);
+                acc = fmaf(wy, row, acc);
+            }
         }
-        acc = fmaf(wy, row, acc);
+    } else {
+        for (int Y = Y_lo; Y <= Y_hi; ++Y) {
+            const float wy = tap_weight(Y, y, H, rh);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int X = X_lo; X <= X_hi; ++X) row = fmaf(tap_weight(X, x, W, rw), gp[(long)(Y - dy) * OW + (X - dx)], row);
+            acc = fmaf(wy, row, acc);
+        }
     }
     gz[plane * (long)H * W + e] = acc;
 }
