@@ -118,7 +118,12 @@ template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
-                                                                    float* __restrict__ out)
+                                                                    float* __restrict__ out,
+                                                                    // grouped / gathered GEMM (TAPS 1, PIXMAJOR): row r of the product reads packed
+                                                                    // pixel rowidx[r] and every 256-row tile has its own 128 output channels
+                                                                    // [tile_co0[tile], +128) of the packed weights; the tile is stored 128 wide
+                                                                    const int32_t* __restrict__ rowidx = nullptr,
+                                                                    const int32_t* __restrict__ tile_co0 = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,16 +131,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     const int nchunk = (Cin + 127) / 128;
     const int npanel = TAPS * nchunk;
     const int hw = H * W;
-    const long ptot = (long)B * hw;
+    const long ptot = rowidx ? (long)B : (long)B * hw;             // grouped form: B carries the number of product rows
     const long pix0 = (long)blockIdx.x * CV_PIX + wave * 32;       // this wave's first pixel (32 consecutive, same image row: W % 32 == 0)
-    const int co0 = blockIdx.y * CV_CO;
+    const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * CV_CO;
     const long pc = min(pix0, ptot - 32);
     const int b = (int)(pc / hw);
     const int prem = (int)(pc - (long)b * hw);
     const int y = prem / W, x0 = prem - y * W;
     // this lane's pixel (b, y, x0 + lr) at tap (0,0) inside a plane of the packed activations: padded coords (y + ky, x + kx)
     const long plane = (long)(H + 2) * (W + 2);
-    const long pixbase = (long)y * (W + 2) + x0 + lr;
+    const long pixbase = rowidx ? (long)max(rowidx[min(pix0, ptot - 32) + lr], 0) : (long)y * (W + 2) + x0 + lr;
 
     // A operand: 8 k-steps x (hi, lo) fragments = 64 VGPRs, single-buffered.  The loop is k-step major (12 MFMAs over the
     // four 32-channel output blocks per k-step), so a k-step's registers are dead right after it and are reloaded with the
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
         const int tap = (TAPS == 1) ? 4 : it / nchunk;
         const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
         const int ky = tap / 3, kx = tap - ky * 3;
-        return xpk + (((long)(b * nchunk + chunk) * 32 + h) * plane + pixbase + (long)ky * (W + 2) + kx) * 16;
+        return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + h) * plane + pixbase + (long)ky * (W + 2) + kx) * 16;
     };
     const long fstride = 2 * plane * 16;                            // fragment 2*ss+h -> 2*(ss+1)+h
     auto load_a = [&](const unsigned char* r, int ss) {
@@ -261,12 +266,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
             const int co = co0 + cb * 32 + lr;
             if (co >= Cout) continue;
             const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+            const int ocol = tile_co0 ? cb * 32 + lr : co;          // grouped form: a compact CV_CO-wide row per product row
+            const int ostride = tile_co0 ? CV_CO : Cout;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const long pix = pix0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 float v = acc[cb][reg] * sc + sh;
                 if (ACT == 1) v = fmaxf(v, 0.f);
-                out[pix * Cout + co] = v;
+                out[pix * ostride + ocol] = v;
             }
         }
         return;
@@ -371,6 +378,26 @@ extern "C" int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const fl
     else { if (res) CV(1, true); else CV(1, false); }
 #undef CV
     return gdm_launch_status("conv3x3_bf16x3_kernel");
+}
+
+// Grouped, gathered GEMM on the same kernel: Y[r, 0:128] = Wpk[tile_co0[r / 256] + 0:128, :] . X[rowidx[r], :] for R rows (R % 256 == 0),
+// X packed by gdm_conv3x3_pack_act_hip(x, 1, Cin, 1, M), weights packed by gdm_conv1x1_pack_weight_hip(Cout_total, Cin).
+extern "C" int gdm_gemm_grouped_hip(const void* xpk, const void* wpk, const int32_t* rowidx, const int32_t* tile_co0, int R, int M,
+                                    int Cin, int Cout_total, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xpk && wpk && rowidx && tile_co0 && out, "gdm_gemm_grouped_hip: NULL pointer");
+    GDM_CHECK_ARG(R >= 256 && R % 256 == 0 && M >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout_total >= 128 && Cout_total % 128 == 0,
+                  "gdm_gemm_grouped_hip: R=%d (multiple of 256) M=%d Cin=%d Cout_total=%d (multiples of 128)", R, M, Cin, Cout_total);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        attr = true;
+    }
+    // the kernel sees B = R "pixels" of a 1 x 1 map for the row bookkeeping and H = 1, W = M for the packed source
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<0, false, 1, true>), dim3(R / CV_PIX, 1), dim3(CV_THREADS), 2 * CV_PANEL, (hipStream_t)stream,
+                       (const unsigned char*)xpk, (const unsigned char*)wpk, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       R, Cin, Cout_total, 1, M, out, rowidx, tile_co0);
+    return gdm_launch_status("gemm_grouped_kernel");
 }
 
 // 1x1 convolution / GEMM on the same kernel (one tap): out = act(scale * (W x) + shift), x packed by gdm_conv3x3_pack_act_hip.

@@ -174,7 +174,46 @@ __global__ __launch_bounds__(128) void spline_direct_kernel(const float* __restr
     }
 }
 
+// Aggregation for the edge-grouped form: Y f32[R,128-wide rows of C] holds x_j . W[wi] for every (source, kernel index) pair that
+// some edge needs (gdm_gemm_grouped_hip); pos i32[E,8] = row of Y for (edge, corner), basis f32[E,8] the corner weights.
+template <bool RELU>
+__global__ __launch_bounds__(128) void spline_pairs_aggregate_kernel(const float* __restrict__ Y, const int32_t* __restrict__ rowptr,
+                                                                     const int32_t* __restrict__ pos, const float* __restrict__ basis,
+                                                                     const float* __restrict__ root, const float* __restrict__ bias,
+                                                                     int C, float* __restrict__ out)
+{
+    const int i = blockIdx.x;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int o = threadIdx.x; o < C; o += blockDim.x) {
+        float acc = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) m += basis[8 * e + s] * Y[(long)pos[8 * e + s] * C + o];
+            acc += m;
+        }
+        const int deg = e1 - e0;
+        float r = deg > 0 ? acc / (float)deg : 0.f;
+        if (root) r += root[(long)i * C + o];
+        if (bias) r += bias[o];
+        if (RELU) r = fmaxf(r, 0.f);
+        out[(long)i * C + o] = r;
+    }
+}
+
 } // namespace
+
+extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                              const float* root, const float* bias, int M, int C, int relu, float* out, void* stream)
+{
+    GDM_CHECK_ARG(Y && rowptr && pos && basis && out, "gdm_spline_pairs_aggregate_hip: NULL pointer");
+    GDM_CHECK_ARG(M >= 1 && C >= 1, "gdm_spline_pairs_aggregate_hip: bad shape");
+    if (relu)
+        hipLaunchKernelGGL(spline_pairs_aggregate_kernel<true>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
+    else
+        hipLaunchKernelGGL(spline_pairs_aggregate_kernel<false>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
+    return gdm_launch_status("spline_pairs_aggregate_kernel");
+}
 
 extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
                                      const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,

@@ -578,6 +578,25 @@ def gemm_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, pixel_major=
     return out
 
 
+def gemm_grouped(x_cm, wpk, rowidx, tile_co0, cout_total):
+    """Grouped, gathered GEMM on the split-bf16 MFMA kernel (include/gdm.h gdm_gemm_grouped_hip): x_cm f32[1,Cin,M] (channel-major),
+    wpk = gemm_pack_weight of a [cout_total, Cin] matrix, rowidx i32[R] (R % 256 == 0), tile_co0 i32[R/256] -> Y f32[R,128]."""
+    x_cm = _dev(x_cm, torch.float32, "x")
+    _, Cin, M = x_cm.shape
+    R = rowidx.shape[0]
+    L = _lib.lib()
+    key = (1, Cin, 1, M, x_cm.device.index, torch.cuda.current_stream().cuda_stream)
+    xpk = _conv_act_cache.get(key)
+    if xpk is None:
+        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(1, Cin, 1, M), dtype=torch.uint8, device=x_cm.device)
+        _conv_act_cache[key] = xpk
+    check(L.gdm_conv3x3_pack_act_hip(x_cm.data_ptr(), 1, Cin, 1, M, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
+    Y = torch.empty((R, 128), dtype=torch.float32, device=x_cm.device)
+    check(L.gdm_gemm_grouped_hip(xpk.data_ptr(), wpk.data_ptr(), rowidx.data_ptr(), tile_co0.data_ptr(), R, M, Cin, cout_total,
+                                 Y.data_ptr(), _stream()), "gdm_gemm_grouped_hip")
+    return Y
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

@@ -29,6 +29,8 @@ from .layers import USE_MFMA_GEMM, cached_gemm_weight
 from .synthetic import COLOR_MEAN, COLOR_STD_MESH
 
 KERNEL_SIZE = 5
+# GDM_GROUPED_SPLINE=0 keeps the 128-channel SplineConv layers on the dense [M, 125*out] GEMM (A/B switch)
+USE_GROUPED_SPLINE = os.environ.get("GDM_GROUPED_SPLINE", "1") != "0"
 
 
 class _SplineAggregate(torch.autograd.Function):
@@ -78,7 +80,7 @@ class SplineConv(nn.Module):
             state_dict[prefix + "lin.weight"] = state_dict.pop(old).t().contiguous()
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x, rowptr, src, attr, relu=False):
+    def forward(self, x, rowptr, src, attr, relu=False, pairs=None):
         M = x.shape[0]
         nk = KERNEL_SIZE ** 3
         if self.cin <= 16 and x.is_cuda and not torch.is_grad_enabled():
@@ -94,6 +96,19 @@ class SplineConv(nn.Module):
             check(_lib.lib().gdm_spline_direct_hip(xc.data_ptr(), self.weight.data_ptr(), rowptr.data_ptr(), src.data_ptr(), attr.data_ptr(),
                                                    cache[1].data_ptr(), self.bias.data_ptr(), M, self.cin, self.cout, KERNEL_SIZE, int(relu),
                                                    out.data_ptr(), ops._stream()), "gdm_spline_direct_hip")
+            return out
+        if (USE_MFMA_GEMM and USE_GROUPED_SPLINE and pairs is not None and not torch.is_grad_enabled() and x.is_cuda
+                and self.cin % 128 == 0 and self.cout == 128):
+            # edge-grouped form: only the (source, kernel index) pairs some edge needs are multiplied (about a quarter of the dense
+            # [M, 125*out] table, which is then never written), on the same split-bf16 MFMA kernel with gathered rows
+            wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin),
+                                        (self.weight,))
+            Y = ops.gemm_grouped(x.t().contiguous().unsqueeze(0), wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout)
+            root = self.lin(x)
+            out = torch.empty((M, self.cout), dtype=torch.float32, device=x.device)
+            check(_lib.lib().gdm_spline_pairs_aggregate_hip(Y.data_ptr(), rowptr.data_ptr(), pairs["pos"].data_ptr(), pairs["basis"].data_ptr(),
+                                                            root.data_ptr(), self.bias.data_ptr(), M, self.cout, int(relu), out.data_ptr(),
+                                                            ops._stream()), "gdm_spline_pairs_aggregate_hip")
             return out
         if (USE_MFMA_GEMM and not torch.is_grad_enabled() and x.is_cuda
                 and ops.gemm_supported(self.cin, nk * self.cout, M)):
@@ -135,6 +150,43 @@ def build_mesh_graph(pos, k=4):
     return torch.stack([row, col], dim=0), cart
 
 
+def build_spline_pairs(src, attr, M, cout=128):
+    """Static bookkeeping of the edge-grouped SplineConv: the unique (source vertex, kernel index) pairs the edges need, sorted by
+    kernel index and padded per kernel index to whole 256-row tiles.  src i32[E] / attr f32[E,3] in CSR (target-sorted) order.
+    -> dict(rowidx i32[R], tile_co0 i32[R/256], pos i32[E,8], basis f32[E,8]).  Same fp32 arithmetic as spline_aggregate_kernel."""
+    ks = KERNEL_SIZE
+    v = attr * float(ks - 1)
+    f = torch.floor(v)
+    fl = f.to(torch.int64)
+    fr = v - f
+    E = src.shape[0]
+    wi = torch.zeros((E, 8), dtype=torch.int64, device=src.device)
+    basis = torch.ones((E, 8), dtype=torch.float32, device=src.device)
+    for s_ in range(8):
+        off = 1
+        for d in range(3):
+            kd = (s_ >> d) & 1
+            wi[:, s_] += ((fl[:, d] + kd) % ks) * off
+            off *= ks
+            basis[:, s_] = basis[:, s_] * (fr[:, d] if kd else 1.0 - fr[:, d])
+    key = wi * M + src.to(torch.int64)[:, None]                       # sorts by kernel index, then source
+    uniq, inv = torch.unique(key.reshape(-1), sorted=True, return_inverse=True)
+    pw = uniq // M                                                     # kernel index of every unique pair
+    counts = torch.bincount(pw, minlength=ks ** 3)
+    padded = (counts + 255) // 256 * 256
+    start = torch.cumsum(padded, 0) - padded                          # first row of each kernel index' block
+    first = torch.cumsum(counts, 0) - counts                          # first unique-pair id of each kernel index
+    row = start[pw] + (torch.arange(uniq.shape[0], device=src.device) - first[pw])
+    R = max(int(padded.sum().item()), 256)
+    rowidx = torch.zeros(R, dtype=torch.int32, device=src.device)
+    rowidx[row] = (uniq % M).to(torch.int32)
+    tile_k = torch.repeat_interleave(torch.arange(ks ** 3, device=src.device), padded // 256)
+    tile_co0 = torch.zeros(R // 256, dtype=torch.int32, device=src.device)
+    tile_co0[: tile_k.shape[0]] = (tile_k * cout).to(torch.int32)
+    return dict(rowidx=rowidx.contiguous(), tile_co0=tile_co0.contiguous(), pos=row[inv].view(E, 8).to(torch.int32).contiguous(),
+                basis=basis.contiguous())
+
+
 class SplineCNN_Mesh(nn.Module):
     def __init__(self, cfg, idx, mesh_in_channels=9, out_channels=128, mesh_coord_dim=3, num_mesh_layers=3,
                  cat=True, lin=True, dropout=0.1, model_points=None):
@@ -169,6 +221,7 @@ class SplineCNN_Mesh(nn.Module):
         # imported); symmetry correspondences are a "next" row, none for the LineMOD/YCB objects benched.
         self.sys_corr_idx = None
         self._csr = None
+        self._pairs = None
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         if prefix + "mesh_graph_edge_index" in state_dict:
@@ -194,13 +247,14 @@ class SplineCNN_Mesh(nn.Module):
             rowptr = torch.zeros(M + 1, dtype=torch.int32, device=ei.device)
             rowptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=M), 0).to(torch.int32)
             self._csr = (rowptr.contiguous(), ei[0][order].to(torch.int32).contiguous(), ea[order].contiguous())
+            self._pairs = build_spline_pairs(self._csr[1], self._csr[2], M, self.out_channels) if ei.is_cuda and self.out_channels == 128 else None
         return self._csr
 
     def forward(self):
         rowptr, src, attr = self._ensure_graph()
         feats = [self.mesh_graph_x]
         for conv in self.mesh_convs:
-            feats.append(conv(feats[-1], rowptr, src, attr, relu=True))   # F.relu(conv(...)) (SplineCNN.py:238-239)
+            feats.append(conv(feats[-1], rowptr, src, attr, relu=True, pairs=self._pairs))   # F.relu(conv(...)) (SplineCNN.py:238-239)
         out = torch.cat(feats, dim=-1) if self.cat else feats[-1]
         out = F.dropout(out, p=self.dropout, training=self.training)
         if self.mesh_final is not None:

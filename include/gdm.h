@@ -171,6 +171,15 @@ int gdm_spline_aggregate_bwd_hip(const float* grad_out, const int32_t* rowptr, c
 int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
                           const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
                           float* out, void* stream);
+/* Edge-grouped form of the 128-channel layers: only the (source vertex, kernel index) pairs that some edge needs are multiplied,
+ * 4x fewer FLOPs than the dense form and no [M, 125*C] table.  gdm_gemm_grouped_hip: Y[r, 0:128] = Wpk[tile_co0[r/256] + 0:128, :] .
+ * X[rowidx[r], :] for R % 256 == 0 rows (pairs sorted by kernel index, groups padded to 256 rows with rowidx = 0), X packed by
+ * gdm_conv3x3_pack_act_hip(x^T, 1, Cin, 1, M), weights by gdm_conv1x1_pack_weight_hip (125*C rows, row = wi*C + co).
+ * gdm_spline_pairs_aggregate_hip: out_i = mean_e sum_s basis[e,s] * Y[pos[e,s]] + root_i + bias. */
+int gdm_gemm_grouped_hip(const void* xpk, const void* wpk, const int32_t* rowidx, const int32_t* tile_co0, int R, int M,
+                         int Cin, int Cout_total, float* out, void* stream);
+int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                   const float* root, const float* bias, int M, int C, int relu, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).
