@@ -69,44 +69,102 @@ __device__ __forceinline__ float tap_weight(int o, int i, int n_in, float r)
     return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
 }
 
+// Both transposes below run on 16x16 tiles of the low-resolution plane: the workgroup first lists, for its 16 rows and 16
+// columns, the (output index, weight) pairs with a non-zero weight (<= TL_MAX each; 4-5 for x2), then every thread sums
+// |rows| x |cols| products -- the per-thread weight arithmetic of the plain gather (~200 instructions per element) is gone.
+// Axes with more contributors than TL_MAX (large magnifications, e.g. the 1x1 pyramid-pooling prior) use the plain loops.
+constexpr int TL = 16, TL_MAX = 6;
+
+struct TapLists {
+    int yo[TL][TL_MAX], xo[TL][TL_MAX];
+    float yw[TL][TL_MAX], xw[TL][TL_MAX];
+    int yn[TL], xn[TL];
+    int overflow;
+};
+
+// thread t < 16 lists row y0+t, thread 16 <= t < 32 lists column x0+(t-16); `shift` = tap offset (output index = sample - shift)
+__device__ __forceinline__ void build_tap_lists(TapLists& L, int y0, int x0, int H, int W, int OH, int OW, float rh, float rw, int dy, int dx)
+{
+    const int t = threadIdx.x;
+    if (t == 0) L.overflow = 0;
+    __syncthreads();
+    if (t < 2 * TL) {
+        const bool isy = t < TL;
+        const int i = (isy ? y0 : x0) + (isy ? t : t - TL);
+        const int n_in = isy ? H : W, n_out = isy ? OH : OW, sh = isy ? dy : dx;
+        const float r = isy ? rh : rw;
+        int cnt = 0;
+        if (i < n_in) {
+            int lo, hi;
+            src_range(i, n_in, n_out, r, lo, hi);
+            lo = max(lo, max(0, sh));                        // the sample and the output pixel it belongs to must both be inside
+            hi = min(hi, n_out - 1 + min(0, sh));
+            for (int o = lo; o <= hi; ++o) {
+                const float w = tap_weight(o, i, n_in, r);
+                if (w != 0.f) {
+                    if (cnt < TL_MAX) {
+                        if (isy) { L.yo[t][cnt] = o - sh; L.yw[t][cnt] = w; }
+                        else { L.xo[t - TL][cnt] = o - sh; L.xw[t - TL][cnt] = w; }
+                    }
+                    ++cnt;
+                }
+            }
+        }
+        if (cnt > TL_MAX) atomicOr(&L.overflow, 1);
+        if (isy) L.yn[t] = min(cnt, TL_MAX);
+        else L.xn[t - TL] = min(cnt, TL_MAX);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float gather_transpose_plain(const float* __restrict__ gp, int y, int x, int H, int W, int OH, int OW,
+                                                        float rh, float rw, int dy, int dx)
+{
+    int Y_lo, Y_hi, X_lo, X_hi;
+    src_range(y, H, OH, rh, Y_lo, Y_hi);
+    src_range(x, W, OW, rw, X_lo, X_hi);
+    Y_lo = max(Y_lo, max(0, dy));
+    Y_hi = min(Y_hi, OH - 1 + min(0, dy));
+    X_lo = max(X_lo, max(0, dx));
+    X_hi = min(X_hi, OW - 1 + min(0, dx));
+    float acc = 0.f;
+    for (int Y = Y_lo; Y <= Y_hi; ++Y) {
+        const float wy = tap_weight(Y, y, H, rh);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int X = X_lo; X <= X_hi; ++X) row = fmaf(tap_weight(X, x, W, rw), gp[(long)(Y - dy) * OW + (X - dx)], row);
+        acc = fmaf(wy, row, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float gather_transpose_tile(const TapLists& L, const float* __restrict__ gp, int ty, int tx, int y, int x,
+                                                       int H, int W, int OH, int OW, float rh, float rw, int dy, int dx)
+{
+    if (L.overflow) return gather_transpose_plain(gp, y, x, H, W, OH, OW, rh, rw, dy, dx);
+    float acc = 0.f;
+    const int ny = L.yn[ty], nx = L.xn[tx];
+    for (int a = 0; a < ny; ++a) {
+        const float* rowp = gp + (long)L.yo[ty][a] * OW;
+        float row = 0.f;
+        for (int b = 0; b < nx; ++b) row = fmaf(L.xw[tx][b], rowp[L.xo[tx][b]], row);
+        acc = fmaf(L.yw[ty][a], row, acc);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ go, int H, int W, int OH, int OW,
                                                                     float rh, float rw, float* __restrict__ gin)
 {
+    __shared__ TapLists L;
     const long plane = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= H * W) return;
-    const int y = e / W, x = e - y * W;
-    int oy_lo, oy_hi, ox_lo, ox_hi;
-    src_range(y, H, OH, rh, oy_lo, oy_hi);
-    src_range(x, W, OW, rw, ox_lo, ox_hi);
-    const float* gp = go + plane * (long)OH * OW;
-    float acc = 0.f;
-    if (oy_hi - oy_lo < 10 && ox_hi - ox_lo < 10) {      // the x2 case: <= 10 candidates per axis, weights formed once per axis
-        float wxs[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) wxs[i] = ox_lo + i <= ox_hi ? tap_weight(ox_lo + i, x, W, rw) : 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int oy = oy_lo + j;
-            const float wy = oy <= oy_hi ? tap_weight(oy, y, H, rh) : 0.f;
-            if (wy != 0.f) {
-                float row = 0.f;
-#pragma unroll
-                for (int i = 0; i < 10; ++i)
-                    if (wxs[i] != 0.f) row = fmaf(wxs[i], gp[(long)oy * OW + ox_lo + i], row);
-                acc = fmaf(wy, row, acc);
-            }
-        }
-    } else {
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            const float wy = tap_weight(oy, y, H, rh);
-            if (wy == 0.f) continue;
-            float row = 0.f;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) row = fmaf(tap_weight(ox, x, W, rw), gp[(long)oy * OW + ox], row);
-            acc = fmaf(wy, row, acc);
-        }
-    }
-    gin[plane * (long)H * W + e] = acc;
+    const int tiles_x = (W + TL - 1) / TL;
+    const int y0 = (blockIdx.x / tiles_x) * TL, x0 = (blockIdx.x % tiles_x) * TL;
+    build_tap_lists(L, y0, x0, H, W, OH, OW, rh, rw, 0, 0);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= H || x >= W) return;
+    gin[plane * (long)H * W + (long)y * W + x] = gather_transpose_tile(L, go + plane * (long)OH * OW, ty, tx, y, x, H, W, OH, OW, rh, rw, 0, 0);
 }
 
 // Single-slope PReLU with its backward (the PSPUpsample activations, pspnet.py:41, on up to 10^8 elements in training):
@@ -270,50 +328,20 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_kernel(const float* __re
 __global__ __launch_bounds__(256) void upconv3x3_gather_bwd_kernel(const float* __restrict__ go, int Cout, int H, int W, int OH, int OW,
                                                                    float rh, float rw, float* __restrict__ gz)
 {
+    __shared__ TapLists L;
     const long plane = blockIdx.y;                       // (b, tap, co)
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= H * W) return;
     const int co = (int)(plane % Cout);
     const int tap = (int)((plane / Cout) % 9);
     const long b = plane / (9L * Cout);
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    const int y = e / W, x = e - y * W;
-    int Y_lo, Y_hi, X_lo, X_hi;
-    src_range(y, H, OH, rh, Y_lo, Y_hi);
-    src_range(x, W, OW, rw, X_lo, X_hi);
-    // sample position Y = oy + dy must itself lie in the image (the forward skips taps that fall outside), and so must oy
-    Y_lo = max(Y_lo, max(0, dy));
-    Y_hi = min(Y_hi, OH - 1 + min(0, dy));
-    X_lo = max(X_lo, max(0, dx));
-    X_hi = min(X_hi, OW - 1 + min(0, dx));
-    const float* gp = go + (b * Cout + co) * (long)OH * OW;
-    float acc = 0.f;
-    if (Y_hi - Y_lo < 10 && X_hi - X_lo < 10) {
-        float wxs[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) wxs[i] = X_lo + i <= X_hi ? tap_weight(X_lo + i, x, W, rw) : 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int Y = Y_lo + j;
-            const float wy = Y <= Y_hi ? tap_weight(Y, y, H, rh) : 0.f;
-            if (wy != 0.f) {
-                float row = 0.f;
-#pragma unroll
-                for (int i = 0; i < 10; ++i)
-                    if (wxs[i] != 0.f) row = fmaf(wxs[i], gp[(long)(Y - dy) * OW + (X_lo + i - dx)], row);
-                acc = fmaf(wy, row, acc);
-            }
-        }
-    } else {
-        for (int Y = Y_lo; Y <= Y_hi; ++Y) {
-            const float wy = tap_weight(Y, y, H, rh);
-            if (wy == 0.f) continue;
-            float row = 0.f;
-            for (int X = X_lo; X <= X_hi; ++X) row = fmaf(tap_weight(X, x, W, rw), gp[(long)(Y - dy) * OW + (X - dx)], row);
-            acc = fmaf(wy, row, acc);
-        }
-    }
-    gz[plane * (long)H * W + e] = acc;
+    const int tiles_x = (W + TL - 1) / TL;
+    const int y0 = (blockIdx.x / tiles_x) * TL, x0 = (blockIdx.x % tiles_x) * TL;
+    build_tap_lists(L, y0, x0, H, W, OH, OW, rh, rw, dy, dx);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= H || x >= W) return;
+    gz[plane * (long)H * W + (long)y * W + x] =
+        gather_transpose_tile(L, go + (b * Cout + co) * (long)OH * OW, ty, tx, y, x, H, W, OH, OW, rh, rw, dy, dx);
 }
 
 // LDS-tiled form of upconv3x3_gather for scale factors <= ~0.5 (the x2 upsampling of PSPUpsample): a workgroup
@@ -634,7 +662,7 @@ extern "C" int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes,
     const long zmax = 65535;
     for (long p0 = 0; p0 < planes; p0 += zmax) {
         const long np = planes - p0 < zmax ? planes - p0 : zmax;
-        dim3 grid(gdm_cdiv((long)H * W, 256), (unsigned)np);
+        dim3 grid(gdm_cdiv(H, TL) * gdm_cdiv(W, TL), (unsigned)np);
         hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                            grad_out + p0 * OH * OW, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), grad_in + p0 * H * W);
     }
@@ -711,7 +739,7 @@ extern "C" int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Co
     GDM_CHECK_ARG(grad_out && grad_z, "gdm_upconv3x3_gather_bwd_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && Cout >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && (long)B * 9 * Cout <= 65535,
                   "gdm_upconv3x3_gather_bwd_hip: bad shape B=%d Cout=%d (B*9*Cout <= 65535)", B, Cout);
-    dim3 grid(gdm_cdiv((long)H * W, 256), (unsigned)(B * 9 * Cout));
+    dim3 grid(gdm_cdiv(H, TL) * gdm_cdiv(W, TL), (unsigned)(B * 9 * Cout));
     hipLaunchKernelGGL(upconv3x3_gather_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad_out, Cout, H, W, OH, OW,
                        scale_ac(H, OH), scale_ac(W, OW), grad_z);
     return gdm_launch_status("upconv3x3_gather_bwd_kernel");
