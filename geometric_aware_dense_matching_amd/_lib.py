@@ -52,6 +52,8 @@ SIGNATURES = {
     "gdm_upsample_bilinear_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
     "gdm_upsample_bilinear_bwd_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),
     "gdm_topk_rows_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp]),
+    "gdm_topk_negdist_hip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gdm_affine_act_maxk_hip": (_i, [_vp, _vp, _vp, ctypes.c_long, _i, ctypes.c_long, _i, _i, _f, _vp, _vp]),
     "gdm_edge_feature_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_edge_feature_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_circle_rows_fwd_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),

@@ -16,14 +16,20 @@ namespace {
 constexpr int TK_BLOCK = 256;
 constexpr int IDX_EMPTY = 0x7fffffff;
 
-template <int KMAX>
+// NEGDIST: `score` is the Gram matrix X^T X of one batch item per n rows and the ranked quantity is dgcnn.py:22-25's
+// pairwise_distance[r][c] = ((-xx[c]) - (-2 * gram[r][c])) - xx[r], formed on the fly with torch's operations in torch's order
+// (bit-identical), instead of four elementwise passes over the [B,n,n] matrix before the top-k.
+template <int KMAX, bool NEGDIST>
 __global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __restrict__ score, long rows, int n, int K,
-                                                             int32_t* __restrict__ idx, float* __restrict__ val)
+                                                             int32_t* __restrict__ idx, float* __restrict__ val,
+                                                             const float* __restrict__ xx = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;                               // whole wave exits together
     const float* s = score + row * n;
+    const float* xb = NEGDIST ? xx + (row / n) * n : nullptr;          // this batch item's squared norms
+    const float xr = NEGDIST ? xb[row % n] : 0.f;
     float dl[KMAX];                                        // key = -score, ascending
     int il[KMAX];
 #pragma unroll
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __rest
         il[i] = IDX_EMPTY;
     }
     for (int c = lane; c < n; c += 64) {
-        const float d = -s[c];
+        const float d = NEGDIST ? -(((-xb[c]) - (-2.f * s[c])) - xr) : -s[c];
         if (d < dl[KMAX - 1]) {
             bool gt_hi = true;
 #pragma unroll
@@ -128,10 +134,24 @@ extern "C" int gdm_topk_rows_hip(const float* score, long rows, int n, int K, in
     GDM_CHECK_ARG(rows >= 1 && n >= 1 && K >= 1 && K <= 32, "gdm_topk_rows_hip: bad shape rows=%ld n=%d K=%d", rows, n, K);
     dim3 grid(gdm_cdiv(rows, TK_BLOCK / 64));
     hipStream_t s = (hipStream_t)stream;
-    if (K <= 8) hipLaunchKernelGGL(topk_rows_kernel<8>, grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val);
-    else if (K <= 16) hipLaunchKernelGGL(topk_rows_kernel<16>, grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val);
-    else hipLaunchKernelGGL(topk_rows_kernel<32>, grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val);
+    if (K <= 8) hipLaunchKernelGGL((topk_rows_kernel<8, false>), grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val, (const float*)nullptr);
+    else if (K <= 16) hipLaunchKernelGGL((topk_rows_kernel<16, false>), grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val, (const float*)nullptr);
+    else hipLaunchKernelGGL((topk_rows_kernel<32, false>), grid, dim3(TK_BLOCK), 0, s, score, rows, n, K, idx, val, (const float*)nullptr);
     return gdm_launch_status("topk_rows_kernel");
+}
+
+extern "C" int gdm_topk_negdist_hip(const float* gram, const float* xx, int B, int n, int K, int32_t* idx, void* stream)
+{
+    GDM_CHECK_ARG(gram && xx && idx, "gdm_topk_negdist_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && n >= 1 && K >= 1 && K <= 32, "gdm_topk_negdist_hip: bad shape B=%d n=%d K=%d", B, n, K);
+    const long rows = (long)B * n;
+    dim3 grid(gdm_cdiv(rows, TK_BLOCK / 64));
+    hipStream_t s = (hipStream_t)stream;
+    float* nov = nullptr;
+    if (K <= 8) hipLaunchKernelGGL((topk_rows_kernel<8, true>), grid, dim3(TK_BLOCK), 0, s, gram, rows, n, K, idx, nov, xx);
+    else if (K <= 16) hipLaunchKernelGGL((topk_rows_kernel<16, true>), grid, dim3(TK_BLOCK), 0, s, gram, rows, n, K, idx, nov, xx);
+    else hipLaunchKernelGGL((topk_rows_kernel<32, true>), grid, dim3(TK_BLOCK), 0, s, gram, rows, n, K, idx, nov, xx);
+    return gdm_launch_status("topk_negdist_kernel");
 }
 
 extern "C" int gdm_edge_feature_hip(const float* x, const int32_t* idx, int B, int C, int n, int K, float* out, void* stream)

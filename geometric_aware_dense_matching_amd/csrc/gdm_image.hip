@@ -167,6 +167,33 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     gin[plane * (long)H * W + (long)y * W + x] = gather_transpose_tile(L, go + plane * (long)OH * OW, ty, tx, y, x, H, W, OH, OW, rh, rw, 0, 0);
 }
 
+// out[plane, i] = max_k act(scale[c] * x[plane, i, k] + shift[c]), c = plane % C: eval-mode BatchNorm + LeakyReLU + the max over the
+// K neighbours of the DGCNN edge convolutions (dgcnn.py:104-117) in one pass (three launches and two [B,64,n,K] round trips otherwise).
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_maxk_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int C, long n, int K4, float slope,
+                                                              float* __restrict__ out)
+{
+    const long plane = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(plane % C);
+    const float a = scale[c], b = shift[c];
+    const float4* xp = reinterpret_cast<const float4*>(x + (plane * n + i) * (long)(4 * K4));
+    float m = -INFINITY;
+    for (int k = 0; k < K4; ++k) {
+        const float4 v = xp[k];
+        float o[4] = {v.x * a + b, v.y * a + b, v.z * a + b, v.w * a + b};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ACT == 1) o[j] = fmaxf(o[j], 0.f);
+            if (ACT == 2) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+            m = fmaxf(m, o[j]);
+        }
+    }
+    out[plane * n + i] = m;
+}
+
 // Single-slope PReLU with its backward (the PSPUpsample activations, pspnet.py:41, on up to 10^8 elements in training):
 // y = x > 0 ? x : a x;  gx = x > 0 ? go : a go;  ga = sum_{x <= 0} x go.  torch's multi-output elementwise backward runs these at
 // ~0.6 TB/s (1.9 ms per call); this is one streaming pass with a block reduction and one atomic per block for ga.
@@ -667,6 +694,21 @@ extern "C" int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes,
                            grad_out + p0 * OH * OW, H, W, OH, OW, scale_ac(H, OH), scale_ac(W, OW), grad_in + p0 * H * W);
     }
     return gdm_launch_status("upsample_bilinear_bwd_kernel");
+}
+
+extern "C" int gdm_affine_act_maxk_hip(const float* x, const float* scale, const float* shift, long planes, int C, long n, int K, int act,
+                                       float slope, float* out, void* stream)
+{
+    GDM_CHECK_ARG(x && scale && shift && out, "gdm_affine_act_maxk_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && planes <= 65535 && C >= 1 && n >= 1 && K >= 4 && K % 4 == 0 && act >= 0 && act <= 2,
+                  "gdm_affine_act_maxk_hip: planes=%ld C=%d n=%ld K=%d (K %% 4 == 0, planes <= 65535)", planes, C, n, K);
+    GDM_CHECK_ARG(((uintptr_t)x & 15) == 0, "gdm_affine_act_maxk_hip: x must be 16-byte aligned");
+    dim3 grid(gdm_cdiv(n, 256), (unsigned)planes);
+    hipStream_t s = (hipStream_t)stream;
+    if (act == 0) hipLaunchKernelGGL(affine_act_maxk_kernel<0>, grid, dim3(256), 0, s, x, scale, shift, C, n, K / 4, slope, out);
+    else if (act == 1) hipLaunchKernelGGL(affine_act_maxk_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, C, n, K / 4, slope, out);
+    else hipLaunchKernelGGL(affine_act_maxk_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, C, n, K / 4, slope, out);
+    return gdm_launch_status("affine_act_maxk_kernel");
 }
 
 extern "C" int gdm_prelu1_hip(const float* x, const float* slope, long n, float* y, void* stream)

@@ -14,15 +14,16 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .layers import folded_bn, fused_eval
 from .synthetic import COLOR_MEAN, COLOR_STD_MESH
 
 
 def knn(x, k):
     """dgcnn.py:21-27: x f32[B,C,n] -> idx i32[B,n,k], nearest first (largest negative squared distance)."""
-    inner = -2 * torch.matmul(x.transpose(2, 1), x)
-    xx = torch.sum(x ** 2, dim=1, keepdim=True)
-    pairwise_distance = -xx - inner - xx.transpose(2, 1)
-    return ops.topk_rows(pairwise_distance, k)
+    gram = torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1)
+    # pairwise_distance = -xx - (-2 * gram) - xx^T is formed inside the top-k kernel (same operations, same order)
+    return ops.topk_negdist(gram, xx, k)
 
 
 def get_graph_feature(x, k=20, idx=None, dim9=False):
@@ -58,21 +59,32 @@ class _DgcnnTrunk(nn.Module):
         self.dp1 = nn.Dropout(dropout)
         self.conv9 = nn.Conv1d(256, feat_dim, kernel_size=1, bias=False)
 
+    def _cba(self, seq, x, maxk=False):
+        """conv + BatchNorm + LeakyReLU (+ max over the neighbour dimension): eval mode folds BN + activation (+ max) into one pass."""
+        if fused_eval(x, self) and (not maxk or (x.dim() == 4 and x.shape[-1] % 4 == 0 and x.shape[0] * seq[0].out_channels <= 65535)):
+            y = seq[0](x)
+            scale, shift = folded_bn(seq[1])
+            slope = float(seq[2].negative_slope)
+            if maxk:
+                return ops.affine_act_maxk(y, scale, shift, ops.ACT_LEAKY, slope)
+            if y.numel() // (y.shape[0] * y.shape[1]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
+                return ops.affine_act(y, scale, shift, ops.ACT_LEAKY, slope)
+            return seq[2](seq[1](y))
+        y = seq(x)
+        return y.max(dim=-1, keepdim=False)[0] if maxk else y
+
     def _embed(self, x):
         num_points = x.size(2)
         x = get_graph_feature(x, k=self.k, dim9=True)
-        x = self.conv2(self.conv1(x))
-        x1 = x.max(dim=-1, keepdim=False)[0]
+        x1 = self._cba(self.conv2, self._cba(self.conv1, x), maxk=True)
         x = get_graph_feature(x1, k=self.k)
-        x = self.conv4(self.conv3(x))
-        x2 = x.max(dim=-1, keepdim=False)[0]
+        x2 = self._cba(self.conv4, self._cba(self.conv3, x), maxk=True)
         x = get_graph_feature(x2, k=self.k)
-        x = self.conv5(x)
-        x3 = x.max(dim=-1, keepdim=False)[0]
-        x = self.conv6(torch.cat((x1, x2, x3), dim=1))
+        x3 = self._cba(self.conv5, x, maxk=True)
+        x = self._cba(self.conv6, torch.cat((x1, x2, x3), dim=1))
         x = x.max(dim=-1, keepdim=True)[0].repeat(1, 1, num_points)
         x = torch.cat((x, x1, x2, x3), dim=1)
-        x = self.conv8(self.conv7(x))
+        x = self._cba(self.conv8, self._cba(self.conv7, x))
         return self.conv9(self.dp1(x))
 
 

@@ -257,6 +257,27 @@ def topk_rows(score, k, return_values=False):
     return (idx, val) if return_values else idx
 
 
+def topk_negdist(gram, xx, k):
+    """Indices of dgcnn.py:22-26 (`pairwise_distance.topk(k)`), from gram f32[B,n,n] = x^T x and xx f32[B,n] = sum_c x^2, without
+    materialising pairwise_distance (same fp32 operations in the same order: identical indices)."""
+    gram = _dev(gram, torch.float32, "gram")
+    xx = _dev(xx, torch.float32, "xx")
+    B, n, _ = gram.shape
+    idx = torch.empty((B, n, k), dtype=torch.int32, device=gram.device)
+    check(_lib.lib().gdm_topk_negdist_hip(gram.data_ptr(), xx.data_ptr(), B, n, k, idx.data_ptr(), _stream()), "gdm_topk_negdist_hip")
+    return idx
+
+
+def affine_act_maxk(x, scale, shift, act=0, slope=0.0):
+    """max over the last (neighbour) dimension of act(scale[c]*x + shift[c]); x f32[B,C,n,K] -> f32[B,C,n].  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, C, n, K = x.shape
+    out = torch.empty((B, C, n), dtype=torch.float32, device=x.device)
+    check(_lib.lib().gdm_affine_act_maxk_hip(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), B * C, C, n, K, act, float(slope),
+                                             out.data_ptr(), _stream()), "gdm_affine_act_maxk_hip")
+    return out
+
+
 class _EdgeFeature(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx):

@@ -194,6 +194,9 @@ int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes, int H, int
  * -> idx i32[rows,K] (descending score, ties by ascending column), val f32[rows,K] or NULL.  K <= 32.
  * edge feature (dgcnn.py:30-56): x f32[B,C,n], idx i32[B,n,K] -> out f32[B,2C,n,K] = cat(x_j - x_i, x_i). */
 int gdm_topk_rows_hip(const float* score, long rows, int n, int K, int32_t* idx, float* val, void* stream);
+/* The same top-k over dgcnn.py:22-25's pairwise_distance without materialising it: gram f32[B,n,n] = X^T X, xx f32[B,n] = sum_c x^2;
+ * ranks ((-xx[c]) - (-2*gram[r][c])) - xx[r] formed with torch's operations in torch's order (bit-identical indices). */
+int gdm_topk_negdist_hip(const float* gram, const float* xx, int B, int n, int K, int32_t* idx, void* stream);
 int gdm_edge_feature_hip(const float* x, const int32_t* idx, int B, int C, int n, int K, float* out, void* stream);
 int gdm_edge_feature_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int K, float* grad_x, void* stream);
 
@@ -239,6 +242,11 @@ int gdm_kabsch_stats_hip(const float* scene_xyz, long scene_bstride, int pt_stri
  * reference's sentinel pose [I | (0,0,-1000)] (evaluator.py:94-96).  The optimal proper rotation is obtained as Horn's unit
  * quaternion (largest eigenvector of a symmetric 4x4, cyclic Jacobi, f64) -- the same R as SVD + reflection fix. */
 int gdm_kabsch_solve_hip(const double* stats, int B, int min_points, float* RT, uint8_t* valid, void* stream);
+
+/* Eval-mode BatchNorm + activation + max over the K neighbours (DGCNN edge convolutions, dgcnn.py:104-117) in one pass:
+ * out[plane,i] = max_k act(scale[c]*x[plane,i,k] + shift[c]), c = plane % C; x f32[planes,n,K], K % 4 == 0, planes <= 65535. */
+int gdm_affine_act_maxk_hip(const float* x, const float* scale, const float* shift, long planes, int C, long n, int K, int act,
+                            float slope, float* out, void* stream);
 
 /* Single-slope PReLU (models/cnn/pspnet.py:41) and its backward, for training: y = x > 0 ? x : a x; grad_x = x > 0 ? go : a go;
  * grad_slope[0] += sum over x <= 0 of x * go (zeroed by the caller).  slope is a DEVICE pointer to the one parameter; n % 4 == 0. */
