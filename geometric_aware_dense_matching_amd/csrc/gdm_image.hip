@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
 struct PspMaps {
     const float* y[4];      // f32[B, C, s, s]
     int s[4];
+    float sy[4], sx[4];     // align_corners scale factors (s-1)/(H-1), (s-1)/(W-1)
 };
 
 __global__ __launch_bounds__(256) void psp_combine_kernel(const float* __restrict__ g, PspMaps maps, const float* __restrict__ bias,
@@ -482,38 +483,44 @@ __global__ __launch_bounds__(256) void psp_combine_kernel(const float* __restric
     const long plane = blockIdx.y;                    // b * C + c
     const int c = (int)(plane % C);
     const int hw = H * W;
-    float sy[4], sx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sy[k] = H > 1 ? (float)(maps.s[k] - 1) / (float)(H - 1) : 0.f;
-        sx[k] = W > 1 ? (float)(maps.s[k] - 1) / (float)(W - 1) : 0.f;
-    }
     const float bc = bias ? bias[c] : 0.f;
-    // the plane's four prior maps (1 + 4 + 9 + 36 floats for the reference's bin sizes) live in LDS: sixteen 4-byte global loads
-    // per output element kept the texture path busy for 134 us on a 67 MB pass
+    // the plane's four prior maps (1 + 4 + 9 + 36 floats for the reference's bin sizes) live in LDS; the align_corners scale
+    // factors come from the host: eight float divisions per thread were most of a one-element-per-thread kernel
     __shared__ float pm[4][64];
-    bool in_lds = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) in_lds = in_lds && maps.s[k] * maps.s[k] <= 64;
-    if (in_lds) {
+    {
         const int k = threadIdx.x >> 6, j = threadIdx.x & 63;
         if (j < maps.s[k] * maps.s[k]) pm[k][j] = maps.y[k][plane * maps.s[k] * maps.s[k] + j];
         __syncthreads();
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        const int oy = i / W, ox = i - oy * W;
-        float v = g[plane * hw + i] + bc;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int S = maps.s[k];
-            const float* m = in_lds ? &pm[k][0] : maps.y[k] + plane * S * S;
-            const float fy = sy[k] * (float)oy, fx = sx[k] * (float)ox;
-            const int y0 = min((int)fy, S - 1), x0 = min((int)fx, S - 1);
-            const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
-            const float ly = fy - (float)y0, lx = fx - (float)x0;
-            v += (1.f - ly) * ((1.f - lx) * m[y0 * S + x0] + lx * m[y0 * S + x1]) + ly * ((1.f - lx) * m[y1 * S + x0] + lx * m[y1 * S + x1]);
+    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < hw; i0 += gridDim.x * 1024) {
+        int oy = i0 / W, ox = i0 - oy * W;
+        float v[4];
+        const bool vec = i0 + 3 < hw;
+        if (vec) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + plane * hw + i0);     // hw % 4 == 0 (checked on the host)
+            v[0] = gv.x; v[1] = gv.y; v[2] = gv.z; v[3] = gv.w;
         }
-        out[plane * hw + i] = fmaxf(v, 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i0 + e < hw) {
+                float acc = (vec ? v[e] : g[plane * hw + i0 + e]) + bc;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int S = maps.s[k];
+                    const float* m = &pm[k][0];
+                    const float fy = maps.sy[k] * (float)oy, fx = maps.sx[k] * (float)ox;
+                    const int y0 = min((int)fy, S - 1), x0 = min((int)fx, S - 1);
+                    const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+                    const float ly = fy - (float)y0, lx = fx - (float)x0;
+                    acc += (1.f - ly) * ((1.f - lx) * m[y0 * S + x0] + lx * m[y0 * S + x1]) + ly * ((1.f - lx) * m[y1 * S + x0] + lx * m[y1 * S + x1]);
+                }
+                v[e] = fmaxf(acc, 0.f);
+            }
+            if (++ox == W) { ox = 0; ++oy; }
+        }
+        if (vec) *reinterpret_cast<float4*>(out + plane * hw + i0) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int e = 0; e < 4 && i0 + e < hw; ++e) out[plane * hw + i0 + e] = v[e];
     }
 }
 
@@ -804,10 +811,16 @@ extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, cons
     GDM_CHECK_ARG(g && y1 && y2 && y3 && y4 && out, "gdm_psp_combine_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && C >= 1 && (long)B * C <= 65535 && H >= 1 && W >= 1 && s1 >= 1 && s2 >= 1 && s3 >= 1 && s4 >= 1,
                   "gdm_psp_combine_hip: bad shape");
+    GDM_CHECK_ARG(s1 <= 8 && s2 <= 8 && s3 <= 8 && s4 <= 8, "gdm_psp_combine_hip: prior maps up to 8x8 (the reference uses 1, 2, 3, 6)");
     PspMaps maps;
     maps.y[0] = y1; maps.y[1] = y2; maps.y[2] = y3; maps.y[3] = y4;
     maps.s[0] = s1; maps.s[1] = s2; maps.s[2] = s3; maps.s[3] = s4;
-    int gx = gdm_cdiv((long)H * W, 256);
+    for (int k = 0; k < 4; ++k) {
+        maps.sy[k] = H > 1 ? (float)(maps.s[k] - 1) / (float)(H - 1) : 0.f;
+        maps.sx[k] = W > 1 ? (float)(maps.s[k] - 1) / (float)(W - 1) : 0.f;
+    }
+    GDM_CHECK_ARG(((long)H * W) % 4 == 0 && (((uintptr_t)g | (uintptr_t)out) & 15) == 0, "gdm_psp_combine_hip: H*W must be a multiple of 4 and the maps 16-byte aligned");
+    int gx = gdm_cdiv((long)H * W, 1024);
     if (gx > 16) gx = 16;
     hipLaunchKernelGGL(psp_combine_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, g, maps, bias, C, H, W, out);
     return gdm_launch_status("psp_combine_kernel");
