@@ -19,30 +19,28 @@ constexpr int IDX_EMPTY = 0x7fffffff;
 // NEGDIST: `score` is the Gram matrix X^T X of one batch item per n rows and the ranked quantity is dgcnn.py:22-25's
 // pairwise_distance[r][c] = ((-xx[c]) - (-2 * gram[r][c])) - xx[r], formed on the fly with torch's operations in torch's order
 // (bit-identical), instead of four elementwise passes over the [B,n,n] matrix before the top-k.
-template <int KMAX, bool NEGDIST>
-__global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __restrict__ score, long rows, int n, int K,
-                                                             int32_t* __restrict__ idx, float* __restrict__ val,
-                                                             const float* __restrict__ xx = nullptr)
+//
+// One wave per row; lane l scans columns l, l+64, ... into a PRIVATE sorted list of KP entries, then the 64 lists are merged
+// by K rounds of wave arg-min.  A lane holds on average K/64 of the row's top K, so short private lists (KP = 4) almost always
+// suffice and make the per-element insertion 4x cheaper; the row is exact iff no lane's KP-th entry is at least as good as
+// the merged K-th -- otherwise (probability ~1e-4 per row on unordered data) the wave redoes the row with KP = KMAX.
+template <int KP, bool NEGDIST>
+__device__ __forceinline__ bool topk_row_pass(const float* __restrict__ s, const float* __restrict__ xb, float xr, int n, int K, int lane,
+                                              long row, int32_t* __restrict__ idx, float* __restrict__ val, bool may_fail)
 {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
-    if (row >= rows) return;                               // whole wave exits together
-    const float* s = score + row * n;
-    const float* xb = NEGDIST ? xx + (row / n) * n : nullptr;          // this batch item's squared norms
-    const float xr = NEGDIST ? xb[row % n] : 0.f;
-    float dl[KMAX];                                        // key = -score, ascending
-    int il[KMAX];
+    float dl[KP];                                          // key = -score, ascending
+    int il[KP];
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
+    for (int i = 0; i < KP; ++i) {
         dl[i] = INFINITY;
         il[i] = IDX_EMPTY;
     }
     for (int c = lane; c < n; c += 64) {
         const float d = NEGDIST ? -(((-xb[c]) - (-2.f * s[c])) - xr) : -s[c];
-        if (d < dl[KMAX - 1]) {
+        if (d < dl[KP - 1]) {
             bool gt_hi = true;
 #pragma unroll
-            for (int i = KMAX - 1; i > 0; --i) {
+            for (int i = KP - 1; i > 0; --i) {
                 const bool gt_lo = dl[i - 1] > d;
                 const float dn = gt_lo ? dl[i - 1] : (gt_hi ? d : dl[i]);
                 const int in = gt_lo ? il[i - 1] : (gt_hi ? c : il[i]);
@@ -54,6 +52,10 @@ __global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __rest
             il[0] = gt_hi ? c : il[0];
         }
     }
+    const float last = dl[KP - 1];                         // this lane's KP-th best (+inf while the list is not full)
+    float outd = 0.f;                                      // round k's winner is kept by lane k until the row is known to be exact
+    int outi = 0;
+    float kth = INFINITY;
     for (int k = 0; k < K; ++k) {
         float bd = dl[0];
         int bi = il[0];
@@ -68,18 +70,44 @@ __global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __rest
         }
         if (dl[0] == bd && il[0] == bi) {
 #pragma unroll
-            for (int i = 0; i < KMAX - 1; ++i) {
+            for (int i = 0; i < KP - 1; ++i) {
                 dl[i] = dl[i + 1];
                 il[i] = il[i + 1];
             }
-            dl[KMAX - 1] = INFINITY;
-            il[KMAX - 1] = IDX_EMPTY;
+            dl[KP - 1] = INFINITY;
+            il[KP - 1] = IDX_EMPTY;
         }
         if (lane == (k & 63)) {
-            idx[row * K + k] = bi == IDX_EMPTY ? 0 : bi;
-            if (val) val[row * K + k] = -bd;
+            outd = bd;
+            outi = bi;
         }
+        kth = bd;
     }
+    // a lane whose full private list ends at or before the merged K-th key may have dropped an element that belongs to the top K
+    if (may_fail && __ballot(last <= kth && last < INFINITY) != 0ull) return false;
+    if (lane < K) {
+        idx[row * K + lane] = outi == IDX_EMPTY ? 0 : outi;
+        if (val) val[row * K + lane] = -outd;
+    }
+    return true;
+}
+
+template <int KMAX, bool NEGDIST>
+__global__ __launch_bounds__(TK_BLOCK) void topk_rows_kernel(const float* __restrict__ score, long rows, int n, int K,
+                                                             int32_t* __restrict__ idx, float* __restrict__ val,
+                                                             const float* __restrict__ xx = nullptr)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;                               // whole wave exits together
+    const float* s = score + row * n;
+    const float* xb = NEGDIST ? xx + (row / n) * n : nullptr;          // this batch item's squared norms
+    const float xr = NEGDIST ? xb[row % n] : 0.f;
+    constexpr int KP = KMAX >= 16 ? 4 : KMAX;
+    if (KP < KMAX && n >= 64 * KP) {
+        if (topk_row_pass<KP, NEGDIST>(s, xb, xr, n, K, lane, row, idx, val, true)) return;
+    }
+    (void)topk_row_pass<KMAX, NEGDIST>(s, xb, xr, n, K, lane, row, idx, val, false);
 }
 
 // out[b, c, i, k] = x[b,c,idx[b,i,k]] - x[b,c,i]   (c < C)
