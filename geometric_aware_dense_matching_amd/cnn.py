@@ -29,6 +29,8 @@ from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fuse
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 # GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
 USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
+# GDM_FUSED_UPCONV=0 keeps the 64 -> 64 up stage on the two-kernel form (low-resolution GEMM + gather) (A/B switch)
+USE_FUSED_UPCONV = os.environ.get("GDM_FUSED_UPCONV", "1") != "0"
 # GDM_LOWRES_UPCONV_TRAIN=0 keeps PSPUpsample's training path on upsample + MIOpen convolution (A/B switch)
 USE_LOWRES_UPCONV_TRAIN = os.environ.get("GDM_LOWRES_UPCONV_TRAIN", "1") != "0"
 
@@ -208,6 +210,16 @@ class PSPUpsample(nn.Module):
                 # conv3x3(up(x)) = 9-tap bilinear gather of a LOW-resolution 1x1 convolution (4x fewer FLOPs, no
                 # 2x-resolution intermediate), BN (with the conv bias) + PReLU folded into the gather's epilogue
                 Bx, Cin, Hx, Wx = x.shape
+                if USE_FUSED_UPCONV and Cin == 64 and conv.out_channels == 64 and Hx >= 2 and Wx >= 2 and Bx <= 65535:
+                    # 64 -> 64 (last up stage): channel mix on the matrix cores into LDS + gather in ONE kernel, no 9*64-channel tensor
+                    w = conv.weight
+                    key = (w._version, w.data_ptr())
+                    cache = self.__dict__.get("_gdm_fused64")
+                    if cache is None or cache[0] != key:
+                        cache = (key, ops.upconv_fused64_pack_weight(w))
+                        self.__dict__["_gdm_fused64"] = cache
+                    scale, shift = folded_bn(self.conv[2], conv.bias)
+                    return ops.upconv_fused64(x, cache[1], scale, shift, (Hx * 2, Wx * 2), code[0], code[1])
                 if USE_MFMA_GEMM and ops.gemm_supported(Cin, 9 * conv.out_channels, Hx * Wx):
                     wpk, c9 = cached_gemm_weight(self, "tap", self._tap_major_weight, (conv.weight,))
                     z = ops.gemm_bf16x3(x.reshape(Bx, Cin, Hx * Wx), wpk, c9).view(Bx, -1, Hx, Wx)      # split-bf16 MFMA

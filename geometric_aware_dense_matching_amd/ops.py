@@ -391,6 +391,28 @@ def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
     return out
 
 
+def upconv_fused64_pack_weight(weight):
+    """conv weight f32[64,64,3,3] -> packed split-bf16 rows for upconv_fused64."""
+    w = _dev(weight.detach(), torch.float32, "weight")
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise ValueError("upconv_fused64_pack_weight: weight must be [64,64,3,3], got %s" % (tuple(w.shape),))
+    L = _lib.lib()
+    wpk = torch.empty(L.gdm_upconv_fused64_weight_bytes(), dtype=torch.uint8, device=w.device)
+    check(L.gdm_upconv_fused64_pack_weight_hip(w.data_ptr(), wpk.data_ptr(), _stream()), "gdm_upconv_fused64_pack_weight_hip")
+    return wpk
+
+
+def upconv_fused64(x, wpk, scale, shift, out_size, act=0, slope=0.0):
+    """act(scale * conv3x3(upsample_bilinear_ac(x)) + shift) for 64 -> 64 channels in one kernel.  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    OH, OW = int(out_size[0]), int(out_size[1])
+    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    check(_lib.lib().gdm_upconv_fused64_hip(x.data_ptr(), wpk.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, C, H, W, OH, OW, act,
+                                            float(slope), out.data_ptr(), _stream()), "gdm_upconv_fused64_hip")
+    return out
+
+
 class _UpconvGather(torch.autograd.Function):
     """out = 9-tap bilinear gather of z (+ bias[co]); differentiable in z and bias (training form of PSPUpsample)."""
 

@@ -271,6 +271,13 @@ int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* sh
 /* Its transpose for training (scale = 1, act = none): grad_z f32[B,9*Cout,H,W] from grad_out f32[B,Cout,OH,OW]; every element of
  * grad_z is written (gather form, no atomics).  B*9*Cout <= 65535. */
 int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Cout, int H, int W, int OH, int OW, float* grad_z, void* stream);
+/* The whole PSPUpsample(64 -> 64) in one kernel (the last up stage, where the 9*64-channel low-resolution tensor of the two-kernel
+ * form is 604 MB at batch 16): x f32[B,64,H,W] -> out f32[B,64,OH,OW] = act(scale * conv3x3(upsample(x)) + shift), weights packed by
+ * gdm_upconv_fused64_pack_weight_hip from the f32[64,64,3,3] convolution weight (split-bf16 products, fp32 accumulate). */
+size_t gdm_upconv_fused64_weight_bytes(void);
+int gdm_upconv_fused64_pack_weight_hip(const float* w, void* wpk, void* stream);
+int gdm_upconv_fused64_hip(const float* x, const void* wpk, const float* scale, const float* shift, int B, int C, int H, int W,
+                           int OH, int OW, int act, float slope, float* out, void* stream);
 
 /* Pyramid-pooling bottleneck tail (pspnet.py:24-31) after splitting the 1x1 convolution over the concat:
  * out = relu(g + bias[c] + sum_k bilinear_align_corners(y_k)), g f32[B,C,H,W] = W_f . feats, y_k f32[B,C,s_k,s_k] = W_k . prior_k. */

@@ -457,3 +457,30 @@ def test_spline_grouped_form_equals_dense_form():
         grouped = conv(x, rowptr, src, attr, relu=True, pairs=pairs)
     assert (dense - grouped).abs().max().item() < 1e-5 * max(1.0, dense.abs().max().item())
     assert pairs["rowidx"].shape[0] < M * 125 // 2          # well under the dense table's row count
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 19, 27), (3, 8, 40)])
+def test_fused_upconv64_equals_upsample_conv_bn_prelu(B, H, W):
+    """PSPUpsample(64,64) in eval: the one-kernel form (MFMA channel mix in LDS + 9-tap gather) == Upsample + Conv3x3 + BN + PReLU in
+    fp64 torch, and == the two-kernel form."""
+    from geometric_aware_dense_matching_amd import cnn
+    torch.manual_seed(B * 7 + H)
+    mod = cnn.PSPUpsample(64, 64).cuda().eval()
+    bn = mod.conv[2]
+    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(B, 64, H, W, device="cuda")
+    with torch.no_grad():
+        cnn.USE_FUSED_UPCONV = True
+        got = mod(x)
+        cnn.USE_FUSED_UPCONV = False
+        two = mod(x)
+        cnn.USE_FUSED_UPCONV = True
+        conv, act = mod.conv[1], mod.conv[3]
+        up = torch.nn.functional.interpolate(x.double(), size=(2 * H, 2 * W), mode="bilinear", align_corners=True)
+        y = torch.nn.functional.conv2d(up, conv.weight.double(), conv.bias.double(), padding=1)
+        y = (y - bn.running_mean.double()[None, :, None, None]) / torch.sqrt(bn.running_var.double() + bn.eps)[None, :, None, None]
+        y = y * bn.weight.double()[None, :, None, None] + bn.bias.double()[None, :, None, None]
+        ref = torch.where(y > 0, y, y * act.weight.double()).float()
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 3e-5 * scale
+    assert (got - two).abs().max().item() < 3e-5 * scale
