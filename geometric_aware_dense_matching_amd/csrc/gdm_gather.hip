@@ -236,6 +236,45 @@ __global__ __launch_bounds__(GB) void att_pool_bwd_kernel(const float* __restric
     }
 }
 
+// K == 16 forms: thread = (row, quarter of the row).  A wave's float4 loads and stores then cover 1 KiB of consecutive addresses
+// (the one-row-per-thread form strides its lanes by 64 B: four times the memory instructions per byte, each touching 64 lines),
+// and the reductions over K are three in-thread operations plus two xor-shuffles inside the 4-lane group.
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); return fmaxf(v, __shfl_xor(v, 2, 64)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1, 64); return v + __shfl_xor(v, 2, 64); }
+
+__global__ __launch_bounds__(GB) void att_pool16_kernel(const float4* __restrict__ att, const float4* __restrict__ feat, long rows,
+                                                        float* __restrict__ out)
+{
+    const long q = (long)blockIdx.x * GB + threadIdx.x;          // quarter-row index; rows * 4 is a multiple of 4, so a 4-lane group is all-in or all-out
+    const bool live = q < rows * 4;
+    const float4 a = live ? att[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 f = live ? feat[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float mx = quad_max(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    const float e0 = expf(a.x - mx), e1 = expf(a.y - mx), e2 = expf(a.z - mx), e3 = expf(a.w - mx);
+    const float den = quad_sum((e0 + e1) + (e2 + e3));
+    const float num = quad_sum((f.x * (e0 / den) + f.y * (e1 / den)) + (f.z * (e2 / den) + f.w * (e3 / den)));
+    if (live && (threadIdx.x & 3) == 0) out[q >> 2] = num;
+}
+
+__global__ __launch_bounds__(GB) void att_pool16_bwd_kernel(const float4* __restrict__ att, const float4* __restrict__ feat,
+                                                            const float* __restrict__ go, long rows, float4* __restrict__ gatt,
+                                                            float4* __restrict__ gfeat)
+{
+    const long q = (long)blockIdx.x * GB + threadIdx.x;
+    const bool live = q < rows * 4;
+    const float4 a = live ? att[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 f = live ? feat[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float g = live ? go[q >> 2] : 0.f;
+    const float mx = quad_max(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    const float e0 = expf(a.x - mx), e1 = expf(a.y - mx), e2 = expf(a.z - mx), e3 = expf(a.w - mx);
+    const float den = quad_sum((e0 + e1) + (e2 + e3));
+    const float s0 = e0 / den, s1 = e1 / den, s2 = e2 / den, s3 = e3 / den;
+    const float outv = quad_sum((s0 * f.x + s1 * f.y) + (s2 * f.z + s3 * f.w));
+    if (!live) return;
+    gfeat[q] = make_float4(g * s0, g * s1, g * s2, g * s3);
+    gatt[q] = make_float4(g * s0 * (f.x - outv), g * s1 * (f.y - outv), g * s2 * (f.z - outv), g * s3 * (f.w - outv));
+}
+
 // seg f32[B,2,N] -> mask u8[B,N], count i32[B]
 __global__ __launch_bounds__(GB) void seg_mask_kernel(const float* __restrict__ seg, int N, uint8_t* __restrict__ mask,
                                                       int32_t* __restrict__ count)
@@ -340,7 +379,9 @@ extern "C" int gdm_att_pool_hip(const float* att, const float* feat, int B, int 
     GDM_CHECK_ARG(att && feat && out, "gdm_att_pool_hip: NULL pointer");
     GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_att_pool_hip: K=%d not in [1,32]", K);
     const long rows = (long)B * C * n;
-    if (K <= 16)
+    if (K == 16 && (((uintptr_t)att | (uintptr_t)feat) & 15) == 0)
+        hipLaunchKernelGGL(att_pool16_kernel, dim3(gdm_cdiv(rows * 4, GB)), dim3(GB), 0, STREAM(stream), (const float4*)att, (const float4*)feat, rows, out);
+    else if (K <= 16)
         hipLaunchKernelGGL(att_pool_kernel<16>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, rows, K, out);
     else
         hipLaunchKernelGGL(att_pool_kernel<32>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, rows, K, out);
@@ -353,7 +394,10 @@ extern "C" int gdm_att_pool_bwd_hip(const float* att, const float* feat, const f
     GDM_CHECK_ARG(att && feat && go && gatt && gfeat, "gdm_att_pool_bwd_hip: NULL pointer");
     GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_att_pool_bwd_hip: K=%d not in [1,32]", K);
     const long rows = (long)B * C * n;
-    if (K <= 16)
+    if (K == 16 && (((uintptr_t)att | (uintptr_t)feat | (uintptr_t)gatt | (uintptr_t)gfeat) & 15) == 0)
+        hipLaunchKernelGGL(att_pool16_bwd_kernel, dim3(gdm_cdiv(rows * 4, GB)), dim3(GB), 0, STREAM(stream), (const float4*)att, (const float4*)feat, go,
+                           rows, (float4*)gatt, (float4*)gfeat);
+    else if (K <= 16)
         hipLaunchKernelGGL(att_pool_bwd_kernel<16>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, go, rows, K, gatt, gfeat);
     else
         hipLaunchKernelGGL(att_pool_bwd_kernel<32>, dim3(gdm_cdiv(rows, GB)), dim3(GB), 0, STREAM(stream), att, feat, go, rows, K, gatt, gfeat);

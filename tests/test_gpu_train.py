@@ -120,7 +120,7 @@ def test_prelu1_forward_backward_equals_torch():
     assert torch.allclose(ga, a.grad, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 24, 8, 9, 13), (1, 16, 5, 32, 32)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 24, 8, 9, 13), (1, 16, 5, 32, 32), (1, 16, 3, 40, 24)])
 def test_pspupsample_lowres_training_path_matches_reference_path(B, Cin, Cout, H, W):
     """Training form of PSPUpsample: low-resolution GEMM + differentiable 9-tap gather == Upsample(x2) + Conv3x3 (outputs and all
     gradients), through train-mode BatchNorm and PReLU."""

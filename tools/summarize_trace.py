@@ -17,12 +17,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--periodic", action="store_true",
+                    help="bench_train.py traces (no kNN launch per step): steps are delimited by a kernel that the trace "
+                         "holds exactly once per step")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "knn_kernel<1>" in r["Kernel_Name"]]
-    # steps: warmup W, timed K, then one more forward before the roofline loop
-    s, e = starts[-(a.steps + 1)], starts[-1]
+    if a.periodic:
+        # a kernel launched exactly once per step (3 warmup + 5 timed steps in bench_train.py) marks the period
+        cnt = collections.Counter(r["Kernel_Name"] for r in rows)
+        total = a.steps + 3
+        marker = next(r["Kernel_Name"] for r in rows if cnt[r["Kernel_Name"]] == total)
+        starts = [i for i, r in enumerate(rows) if r["Kernel_Name"] == marker]
+        s, e = starts[-(a.steps + 1)], starts[-1]
+    else:
+        starts = [i for i, r in enumerate(rows) if "knn_kernel<1>" in r["Kernel_Name"]]
+        # steps: warmup W, timed K, then one more forward before the roofline loop
+        s, e = starts[-(a.steps + 1)], starts[-1]
     win = rows[s:e]
     t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
     agg = collections.OrderedDict()
