@@ -33,6 +33,8 @@ USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
 USE_FUSED_UPCONV = os.environ.get("GDM_FUSED_UPCONV", "1") != "0"
 # GDM_LOWRES_UPCONV_TRAIN=0 keeps PSPUpsample's training path on upsample + MIOpen convolution (A/B switch)
 USE_LOWRES_UPCONV_TRAIN = os.environ.get("GDM_LOWRES_UPCONV_TRAIN", "1") != "0"
+# GDM_SPLIT_PSP_TRAIN=0 keeps PSPModule's training path on upsampled priors + concat + the 5F-channel bottleneck convolution (A/B switch)
+USE_SPLIT_PSP_TRAIN = os.environ.get("GDM_SPLIT_PSP_TRAIN", "1") != "0"
 
 
 def _conv3x3(cin, cout, stride=1, dilation=1):
@@ -164,15 +166,30 @@ class PSPModule(nn.Module):
                 wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
                 g = ops.gemm_bf16x3(feats.reshape(B, Cin, h * w), wpk, co).view(B, -1, h, w)
             else:
-                g = torch.matmul(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
+                g = ops.wx(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
             sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
-            pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and 36 <= h * w <= 4096 and h >= 6 and w >= 6 else None
+            pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w) else None
             ys = []
             for k, (st, m) in enumerate(zip(self.stages, ms)):
                 p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
                 s_ = p.shape[2]
-                ys.append(torch.matmul(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
+                ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
             return ops.psp_combine(g, ys, self.bottleneck.bias)
+        sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
+        if (USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
+                and (h * w) % 4 == 0 and feats.shape[0] * self.bottleneck.out_channels <= 65535 and h <= 64 and w <= 64):
+            # training: the same algebra as the eval path, under autograd.  W cat(up(V_k pool_k f)..., f) = W_f f + sum_k up((W_k V_k) pool_k f):
+            # the big GEMM has K = F instead of 5F in forward, dgrad and wgrad, the four full-resolution priors and their concat are
+            # never built, one launch pools, one launch adds the priors + bias + ReLU; their backwards are single-pass kernels too
+            B, F_ = feats.shape[0], feats.shape[1]
+            w2 = self.bottleneck.weight.view(self.bottleneck.out_channels, -1)
+            g = ops.wx(w2[:, 4 * F_:], feats.reshape(B, F_, h * w)).view(B, -1, h, w)
+            pools = ops.psp_pools(feats)
+            ys = []
+            for k, st in enumerate(self.stages):
+                m = w2[:, k * F_:(k + 1) * F_] @ st[1].weight.view(F_, F_)
+                ys.append(ops.wx(m, pools[k].reshape(B, F_, sizes[k] * sizes[k])).view(B, -1, sizes[k], sizes[k]))
+            return ops.psp_combine_train(g, ys, self.bottleneck.bias)
         priors = [ops.upsample_bilinear(stage(feats), (h, w)) for stage in self.stages] + [feats]
         return self.relu(self.bottleneck(torch.cat(priors, 1)))
 
@@ -224,7 +241,7 @@ class PSPUpsample(nn.Module):
                     wpk, c9 = cached_gemm_weight(self, "tap", self._tap_major_weight, (conv.weight,))
                     z = ops.gemm_bf16x3(x.reshape(Bx, Cin, Hx * Wx), wpk, c9).view(Bx, -1, Hx, Wx)      # split-bf16 MFMA
                 else:
-                    z = torch.matmul(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
+                    z = ops.wx(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
                 scale, shift = folded_bn(self.conv[2], conv.bias)
                 return ops.upconv3x3_gather(z, scale, shift, conv.out_channels, (x.shape[2] * 2, x.shape[3] * 2), code[0], code[1])
         act = self.conv[3]
@@ -235,7 +252,7 @@ class PSPUpsample(nn.Module):
                 # 9-tap gather: 4x fewer FLOPs forward and backward, no 2x-resolution input, MIOpen's fp32 wrw / bwd-data not needed
                 Bx, Cin, Hx, Wx = x.shape
                 w9 = conv.weight.permute(2, 3, 0, 1).reshape(9 * conv.out_channels, Cin)
-                z = torch.matmul(w9, x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)
+                z = ops.wx(w9, x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)
                 y = self.conv[2](ops.upconv3x3_gather_train(z, conv.bias, conv.out_channels, (Hx * 2, Wx * 2)))
             else:
                 y = self.conv[2](conv(self.conv[0](x)))

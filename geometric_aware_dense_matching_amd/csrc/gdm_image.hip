@@ -167,6 +167,37 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     gin[plane * (long)H * W + (long)y * W + x] = gather_transpose_tile(L, go + plane * (long)OH * OW, ty, tx, y, x, H, W, OH, OW, rh, rw, 0, 0);
 }
 
+// The same transpose for SMALL source maps (the pyramid-pooling priors, 1x1 .. 8x8 -> 32x32): every source pixel collects from a large
+// part of the output, so the tile form above overflows its lists and falls back to per-element loops over the whole output with
+// a few threads per plane (0.42 ms per call on 24 x 512 planes).  Here a workgroup owns a plane: grad_out in LDS, then the
+// separable sums  t[Y][j] = sum_X wx(X, j) go[Y][X],  gin[i][j] = sum_Y wy(Y, i) t[Y][j]  (the order of gather_transpose_plain).
+constexpr int USM_IN = 8, USM_OUT = 4096, USM_OW = 64;
+
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_small_kernel(const float* __restrict__ go, int H, int W, int OH, int OW,
+                                                                          float rh, float rw, float* __restrict__ gin)
+{
+    __shared__ float g[USM_OUT];
+    __shared__ float tsum[USM_OW * USM_IN];              // [OH][W]
+    const long plane = blockIdx.x;
+    const int t = threadIdx.x, ohw = OH * OW;
+    const float* gp = go + plane * ohw;
+    for (int i = t; i < ohw; i += 256) g[i] = gp[i];
+    __syncthreads();
+    for (int e = t; e < OH * W; e += 256) {
+        const int Y = e / W, j = e - Y * W;
+        float row = 0.f;
+        for (int X = 0; X < OW; ++X) row = fmaf(tap_weight(X, j, W, rw), g[Y * OW + X], row);
+        tsum[e] = row;
+    }
+    __syncthreads();
+    for (int e = t; e < H * W; e += 256) {
+        const int i = e / W, j = e - i * W;
+        float acc = 0.f;
+        for (int Y = 0; Y < OH; ++Y) acc = fmaf(tap_weight(Y, i, H, rh), tsum[Y * W + j], acc);
+        gin[plane * (long)(H * W) + e] = acc;
+    }
+}
+
 // out[plane, i] = max_k act(scale[c] * x[plane, i, k] + shift[c]), c = plane % C: eval-mode BatchNorm + LeakyReLU + the max over the
 // K neighbours of the DGCNN edge convolutions (dgcnn.py:104-117) in one pass (three launches and two [B,64,n,K] round trips otherwise).
 template <int ACT>
@@ -772,6 +803,46 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
     if (o && gl == 0) o[bi] = acc / (float)cnt;
 }
 
+// Backward of the four pools in one pass: gin[y][x] = sum over the bins (of every size) that contain (y, x) of grad_bin / bin area.
+// Replaces four adaptive_avg_pool2d backward launches (three of them atomic scatter kernels, 0.5 ms each on 24 x 512 planes of 32 x 32)
+// and the three full-size additions that merge their results.
+__global__ __launch_bounds__(256) void psp_pools_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ g3,
+                                                            const float* __restrict__ g6, int H, int W, float* __restrict__ gin)
+{
+    __shared__ float gs[50];                             // 1 | 4 | 9 | 36 bins, already divided by their areas
+    const long plane = blockIdx.x;
+    const int t = threadIdx.x;
+    if (t < 50) {
+        int s, bi;
+        const float* gsrc;
+        if (t < 1) { s = 1; bi = 0; gsrc = g1 + plane; }
+        else if (t < 5) { s = 2; bi = t - 1; gsrc = g2 + plane * 4; }
+        else if (t < 14) { s = 3; bi = t - 5; gsrc = g3 + plane * 9; }
+        else { s = 6; bi = t - 14; gsrc = g6 + plane * 36; }
+        const int by = bi / s, bx = bi - by * s;
+        const int cnt = (((by + 1) * H + s - 1) / s - (by * H) / s) * (((bx + 1) * W + s - 1) / s - (bx * W) / s);
+        gs[t] = gsrc[bi] / (float)cnt;
+    }
+    __syncthreads();
+    const int hw = H * W;
+    for (int p = t; p < hw; p += 256) {
+        const int y = p / W, x = p - y * W;
+        float acc = 0.f;
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 3 : 6;
+            for (int by = 0; by < s; ++by) {
+                if (y < (by * H) / s || y >= ((by + 1) * H + s - 1) / s) continue;
+                for (int bx = 0; bx < s; ++bx)
+                    if (x >= (bx * W) / s && x < ((bx + 1) * W + s - 1) / s) acc += gs[base + by * s + bx];
+            }
+            base += s * s;
+        }
+        gin[plane * hw + p] = acc;
+    }
+}
+
 // depth (metres) -> camera-frame xyz for a crop window of a frame, as dpt_2_pcld + the integer crop of the loader
 // (/root/reference/datasets/lm/linemod_pbr.py:398-411,473): x = (u - cx) d / fx, y = (v - cy) d / fy, z = d, zeros where d <= 1e-8.
 // depth f32[B,H,W]; K f32[B,3,3]; crop origin (x0,y0) i32[B,2]; out f32[B,S,S,3].
@@ -818,6 +889,11 @@ extern "C" int gdm_upsample_bilinear_bwd_hip(const float* grad_out, long planes,
 {
     GDM_CHECK_ARG(grad_out && grad_in, "gdm_upsample_bilinear_bwd_hip: NULL pointer");
     GDM_CHECK_ARG(planes >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && OH <= 65535, "gdm_upsample_bilinear_bwd_hip: bad shape");
+    if (H <= USM_IN && W <= USM_IN && OH <= USM_OW && OW <= USM_OW && OH * OW <= USM_OUT && planes <= 0x7fffffffL) {
+        hipLaunchKernelGGL(upsample_bilinear_bwd_small_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, grad_out, H, W, OH, OW,
+                           scale_ac(H, OH), scale_ac(W, OW), grad_in);
+        return gdm_launch_status("upsample_bilinear_bwd_small_kernel");
+    }
     const long zmax = 65535;
     for (long p0 = 0; p0 < planes; p0 += zmax) {
         const long np = planes - p0 < zmax ? planes - p0 : zmax;
@@ -988,6 +1064,15 @@ extern "C" int gdm_psp_pools_hip(const float* x, long planes, int H, int W, floa
     GDM_CHECK_ARG(planes >= 1 && H >= 6 && W >= 6 && H * W <= 64 * 64, "gdm_psp_pools_hip: map %dx%d must be between 6x6 and 64x64 pixels", H, W);
     hipLaunchKernelGGL(psp_pools_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, H, W, o1, o2, o3, o6);
     return gdm_launch_status("psp_pools_kernel");
+}
+
+extern "C" int gdm_psp_pools_bwd_hip(const float* g1, const float* g2, const float* g3, const float* g6, long planes, int H, int W,
+                                     float* grad_x, void* stream)
+{
+    GDM_CHECK_ARG(g1 && g2 && g3 && g6 && grad_x, "gdm_psp_pools_bwd_hip: NULL pointer");
+    GDM_CHECK_ARG(planes >= 1 && H >= 6 && W >= 6 && H * W <= 64 * 64, "gdm_psp_pools_bwd_hip: map %dx%d must be between 6x6 and 64x64 pixels", H, W);
+    hipLaunchKernelGGL(psp_pools_bwd_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, g1, g2, g3, g6, H, W, grad_x);
+    return gdm_launch_status("psp_pools_bwd_kernel");
 }
 
 extern "C" int gdm_depth_to_xyz_hip(const float* depth, const float* K, const int32_t* origin, int B, int H, int W, int S,

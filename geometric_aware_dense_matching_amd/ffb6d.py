@@ -128,7 +128,7 @@ class FFB6DEmb(nn.Module):
             code = act_code(getattr(fuse_layer, "activation", None))
             if code is not None:
                 wa, wb = self._split_fuse_weight(fuse_layer, c)
-                t = torch.matmul(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
+                t = ops.wx(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
                 if c == 64 and wa.shape[0] == 64:
                     # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
@@ -139,7 +139,7 @@ class FFB6DEmb(nn.Module):
                     wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
                     x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA
                 else:
-                    x = torch.matmul(wa, rgb_emb0.reshape(bs, c, hr * wr))                    # [B,Cout,HW]
+                    x = ops.wx(wa, rgb_emb0.reshape(bs, c, hr * wr))                    # [B,Cout,HW]
                 scale, shift = folded_bn(fuse_layer.normlayer.bn)
                 y = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1])
                 return y.view(bs, -1, hr, wr)

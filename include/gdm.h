@@ -312,6 +312,10 @@ int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias
 /* The four adaptive average pools (1,2,3,6 bins) of the pyramid pooling module (pspnet.py:17-20) in one pass:
  * x f32[planes,H,W] -> o1 f32[planes,1], o2 [planes,4], o3 [planes,9], o6 [planes,36] (PyTorch bin edges). */
 int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, float* o2, float* o3, float* o6, void* stream);
+/* Its backward (training): grad_x[planes,H,W] = sum over every bin containing the pixel of grad_bin / bin area, all four sizes in one
+ * pass (replaces four adaptive_avg_pool2d backward launches of `PSPModule.stages`, pspnet.py:17-20, and the sums that merge them). */
+int gdm_psp_pools_bwd_hip(const float* g1, const float* g2, const float* g3, const float* g6, long planes, int H, int W,
+                          float* grad_x, void* stream);
 
 /* 1x1 convolution / GEMM on the same split-bf16 MFMA kernel (one tap): x packed by gdm_conv3x3_pack_act_hip, weights
  * f32[Cout,Cin] packed by gdm_conv1x1_pack_weight_hip.  out = act(scale*(W x)+shift) as f32[B,Cout,H,W], or, with
