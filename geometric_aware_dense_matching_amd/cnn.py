@@ -29,6 +29,8 @@ from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fuse
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 # GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
 USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
+# GDM_MFMA_CONV_TRAIN=0 keeps the training forward / input-gradient of those convolutions on MIOpen (A/B switch)
+USE_MFMA_CONV_TRAIN = os.environ.get("GDM_MFMA_CONV_TRAIN", "1") != "0"
 # GDM_FUSED_UPCONV=0 keeps the 64 -> 64 up stage on the two-kernel form (low-resolution GEMM + gather) (A/B switch)
 USE_FUSED_UPCONV = os.environ.get("GDM_FUSED_UPCONV", "1") != "0"
 # GDM_LOWRES_UPCONV_TRAIN=0 keeps PSPUpsample's training path on upsample + MIOpen convolution (A/B switch)
@@ -61,6 +63,14 @@ class BasicBlock(nn.Module):
             conv.__dict__["_gdm_wpk"] = cache
         return cache[1]
 
+    @staticmethod
+    def _train_conv(conv, x):
+        """Training: forward and input gradient of the 32x32-resolution 3x3 convolutions on the split-bf16 MFMA kernel (MIOpen's fp32
+        Winograd runs them 3x slower); the weight gradient stays with MIOpen."""
+        if USE_MFMA_CONV_TRAIN and conv.bias is None and ops.conv3x3_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation):
+            return ops.conv3x3_train(x, conv.weight)
+        return conv(x)
+
     def _mfma_ok(self, x):
         return (USE_MFMA_CONV and ops.conv3x3_supported(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation)
                 and ops.conv3x3_supported(x, self.conv2.weight, self.conv2.stride, self.conv2.padding, self.conv2.dilation)
@@ -89,8 +99,8 @@ class BasicBlock(nn.Module):
                 return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=x)
             sd, bd = folded_bn(self.downsample[1])
             return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=self.downsample[0](x), res_scale=sd, res_shift=bd)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.relu(self.bn1(self._train_conv(self.conv1, x)))
+        out = self.bn2(self._train_conv(self.conv2, out))
         residual = x if self.downsample is None else self.downsample(x)
         out = out + residual
         return self.relu(out)

@@ -652,6 +652,32 @@ def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None)
     return out
 
 
+class _Conv3x3Train(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return conv3x3_bf16x3(x, conv3x3_pack_weight(weight), weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        go = _dev(go, torch.float32, "grad")
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # dgrad of a 3x3/s1/p1 convolution = the same convolution of grad_out with the flipped, transposed filter
+            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+            gx = conv3x3_bf16x3(go, conv3x3_pack_weight(wt), weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return gx, gw
+
+
+def conv3x3_train(x, weight):
+    """Differentiable 3x3/s1/p1 convolution without bias: forward and input gradient on the split-bf16 MFMA kernel (same error bound as
+    the inference kernel, ~1e-5 relative), weight gradient on MIOpen.  Shapes as conv3x3_supported."""
+    return _Conv3x3Train.apply(x, weight)
+
+
 def gemm_supported(cin, cout, npix):
     """K in whole 128-channel chunks (or exactly 64); output channels are padded to 128 inside the kernel (zero weight rows, masked stores), which
     pays once the padding wastes at most a third of the MFMA work."""

@@ -197,3 +197,21 @@ def test_pspmodule_split_training_path_matches_reference_path(B, F, Cout, H, W):
     for a, b in zip(res[False], res[True]):
         scale = max(1.0, a.abs().max().item())
         assert (a - b).abs().max().item() < 2e-4 * scale
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 256, 32, 32), (1, 256, 128, 8, 64)])
+def test_conv3x3_train_matches_autograd_of_conv2d(B, Cin, Cout, H, W):
+    """Training form of the trunk's 3x3 convolutions: forward + input gradient on the split-bf16 MFMA kernel, weight gradient on MIOpen."""
+    from geometric_aware_dense_matching_amd import ops
+    torch.manual_seed(Cin)
+    x = torch.randn(B, Cin, H, W, device="cuda", requires_grad=True)
+    wgt = (torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    w = torch.randn(B, Cout, H, W, device="cuda")
+    y = ops.conv3x3_train(x, wgt)
+    (y * w).sum().backward()
+    got = [y.detach().clone(), x.grad.clone(), wgt.grad.clone()]
+    x.grad = None; wgt.grad = None
+    yr = torch.nn.functional.conv2d(x.double(), wgt.double(), padding=1)
+    (yr * w.double()).sum().backward()
+    for a, b in zip(got, [yr.detach(), x.grad, wgt.grad]):
+        assert (a.double() - b.double()).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
