@@ -39,6 +39,14 @@ USE_LOWRES_UPCONV_TRAIN = os.environ.get("GDM_LOWRES_UPCONV_TRAIN", "1") != "0"
 USE_SPLIT_PSP_TRAIN = os.environ.get("GDM_SPLIT_PSP_TRAIN", "1") != "0"
 
 
+def bn_act(bn, x, relu=None):
+    """relu(bn(x)) (relu optional): the fused training kernels where they apply, the modules otherwise."""
+    if ops.bn_train_supported(x, bn):
+        return ops.batch_norm_act_train(x, bn, ops.ACT_RELU if relu is not None else ops.ACT_NONE)
+    y = bn(x)
+    return relu(y) if relu is not None else y
+
+
 def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
@@ -99,9 +107,9 @@ class BasicBlock(nn.Module):
                 return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=x)
             sd, bd = folded_bn(self.downsample[1])
             return ops.affine_act(self.conv2(out), s2, b2, ops.ACT_RELU, res=self.downsample[0](x), res_scale=sd, res_shift=bd)
-        out = self.relu(self.bn1(self._train_conv(self.conv1, x)))
-        out = self.bn2(self._train_conv(self.conv2, out))
-        residual = x if self.downsample is None else self.downsample(x)
+        out = bn_act(self.bn1, self._train_conv(self.conv1, x), self.relu)
+        out = bn_act(self.bn2, self._train_conv(self.conv2, out))
+        residual = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x))
         out = out + residual
         return self.relu(out)
 
@@ -263,9 +271,9 @@ class PSPUpsample(nn.Module):
                 Bx, Cin, Hx, Wx = x.shape
                 w9 = conv.weight.permute(2, 3, 0, 1).reshape(9 * conv.out_channels, Cin)
                 z = ops.wx(w9, x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)
-                y = self.conv[2](ops.upconv3x3_gather_train(z, conv.bias, conv.out_channels, (Hx * 2, Wx * 2)))
+                y = bn_act(self.conv[2], ops.upconv3x3_gather_train(z, conv.bias, conv.out_channels, (Hx * 2, Wx * 2)))
             else:
-                y = self.conv[2](conv(self.conv[0](x)))
+                y = bn_act(self.conv[2], conv(self.conv[0](x)))
             if y.numel() % 4 == 0:
                 return ops.prelu1(y, act.weight)           # torch's PReLU backward runs at ~0.6 TB/s on these 10^8-element maps
             return act(y)

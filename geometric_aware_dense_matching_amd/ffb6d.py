@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .cnn import PSPNet
+from .cnn import PSPNet, bn_act
 from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
 from .randla import DilatedResBlock
 
@@ -152,7 +152,8 @@ class FFB6DEmb(nn.Module):
             s0, b0 = folded_bn(pre[1])
             rgb_emb = pre[3](ops.affine_act(pre[0](inputs["rgb"]), s0, b0, ops.ACT_RELU))
         else:
-            rgb_emb = self.cnn_pre_stages(inputs["rgb"])
+            pre = self.cnn_pre_stages
+            rgb_emb = pre[3](bn_act(pre[1], pre[0](inputs["rgb"]), pre[2]))
         p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
 
         ds_emb = []

@@ -71,6 +71,17 @@ def act_code(act):
     return None
 
 
+def train_act_code(act):
+    """(ops.ACT_*, slope) of an activation the fused training BatchNorm folds in (fixed slopes only); None otherwise."""
+    if act is None:
+        return ops.ACT_NONE, 0.0
+    if isinstance(act, nn.ReLU):
+        return ops.ACT_RELU, 0.0
+    if isinstance(act, nn.LeakyReLU):
+        return ops.ACT_LEAKY, float(act.negative_slope)
+    return None
+
+
 class _FusedConvMixin:
     _bn_name = None
 
@@ -82,6 +93,15 @@ class _FusedConvMixin:
                 y = self.conv(x)
                 scale, shift = folded_bn(bnw.bn)
                 return ops.affine_act(y, scale, shift, code[0], code[1])
+        if bnw is not None and self.training:
+            act = getattr(self, "activation", None)
+            code = train_act_code(act)
+            if code is not None:
+                y = self.conv(x)
+                if ops.bn_train_supported(y, bnw.bn):
+                    return ops.batch_norm_act_train(y, bnw.bn, code[0], code[1])
+                y = bnw(y)
+                return act(y) if act is not None else y
         return nn.Sequential.forward(self, x)
 
 

@@ -378,6 +378,66 @@ def affine_act(x, scale, shift, act=ACT_NONE, slope=0.0, res=None, res_scale=Non
     return y
 
 
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slope):
+        x = _dev(x, torch.float32, "x")
+        B, C = x.shape[0], x.shape[1]
+        inner = x.numel() // (B * C)
+        L = _lib.lib()
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(L.gdm_bn_stats_hip(x.data_ptr(), B, C, inner, sums.data_ptr(), _stream()), "gdm_bn_stats_hip")
+        check(L.gdm_bn_fwd_apply_hip(x.data_ptr(), sums.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, C, inner, float(eps), float(momentum),
+                                     act, float(slope), saved.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
+                                     running_var.data_ptr() if running_var is not None else None, y.data_ptr(), _stream()), "gdm_bn_fwd_apply_hip")
+        ctx.save_for_backward(x, weight, saved)
+        ctx.act, ctx.slope = act, float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight, saved = ctx.saved_tensors
+        go = _dev(go, torch.float32, "grad")
+        B, C = x.shape[0], x.shape[1]
+        inner = x.numel() // (B * C)
+        L = _lib.lib()
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x)
+        check(L.gdm_bn_bwd_reduce_hip(x.data_ptr(), go.data_ptr(), saved.data_ptr(), B, C, inner, ctx.act, ctx.slope, sums.data_ptr(), _stream()),
+              "gdm_bn_bwd_reduce_hip")
+        check(L.gdm_bn_bwd_apply_hip(x.data_ptr(), go.data_ptr(), sums.data_ptr(), weight.data_ptr(), saved.data_ptr(), B, C, inner, ctx.act, ctx.slope,
+                                     gw.data_ptr(), gb.data_ptr(), gx.data_ptr(), _stream()), "gdm_bn_bwd_apply_hip")
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+USE_FUSED_BN_TRAIN = __import__("os").environ.get("GDM_FUSED_BN_TRAIN", "1") != "0"
+
+
+def bn_train_supported(x, bn):
+    """Plain (not Sync) affine BatchNorm in training mode with torch-style running statistics, on a contiguous f32 GPU map whose inner
+    size is a multiple of 4."""
+    if not (USE_FUSED_BN_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous()):
+        return False
+    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d) or not bn.affine or bn.momentum is None or not bn.track_running_stats:
+        return False
+    B, C = x.shape[0], x.shape[1]
+    inner = x.numel() // max(B * C, 1)
+    return B * C <= 65535 and inner >= 4 and inner % 4 == 0 and x.data_ptr() % 16 == 0 and B * inner > 1
+
+
+def batch_norm_act_train(x, bn, act=ACT_NONE, slope=0.0):
+    """Training-mode `act(bn(x))` (batch statistics, running statistics updated as nn.BatchNorm does) with a fused backward.
+    act: ACT_NONE / ACT_RELU / ACT_LEAKY(slope).  Caller checks bn_train_supported."""
+    y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, slope)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return y
+
+
 def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
     """z f32[B, 9*cout, H, W] (low-resolution tap-major channel mixes) -> f32[B, cout, OH, OW]: the 9-tap bilinear
     gather that completes conv3x3(upsample(x)) + folded BN + activation.  Inference only."""

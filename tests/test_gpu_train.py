@@ -215,3 +215,41 @@ def test_conv3x3_train_matches_autograd_of_conv2d(B, Cin, Cout, H, W):
     (yr * w.double()).sum().backward()
     for a, b in zip(got, [yr.detach(), x.grad, wgt.grad]):
         assert (a.double() - b.double()).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,act", [((4, 16, 32, 32), 1), ((3, 8, 100), 2), ((2, 5, 12, 16), 0), ((24, 64, 64, 64), 1), ((1, 7, 8), 2)])
+def test_fused_batchnorm_act_training_matches_modules(shape, act):
+    """Training-mode BatchNorm + activation (gdm_bn_*): output, running statistics and all gradients == nn.BatchNorm + activation."""
+    from geometric_aware_dense_matching_amd import ops
+    torch.manual_seed(len(shape) * 7 + act)
+    C = shape[1]
+    cls = torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d
+    kw = dict(eps=1e-6, momentum=0.99) if act == 2 else {}
+    bn_a, bn_b = cls(C, **kw).cuda().train(), cls(C, **kw).cuda().train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C)); bn_a.bias.copy_(torch.randn(C))
+        bn_a.running_mean.copy_(torch.randn(C)); bn_a.running_var.copy_(torch.rand(C) + 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    bn_b = bn_b.double()                                   # fp64 reference (MIOpen's fp32 sums are themselves ~1e-5 off at 10^5 elements)
+    x = (torch.randn(*shape, device="cuda") * 2 + 0.7)
+    w = torch.randn(*shape, device="cuda")
+    xa = x.clone().requires_grad_(True)
+    xb = x.double().requires_grad_(True)
+    assert ops.bn_train_supported(xa, bn_a)
+    ya = ops.batch_norm_act_train(xa, bn_a, act, 0.2)
+    pre = bn_b(xb)
+    # the activation's branch is taken from the fp32 result: where |bn(x)| is at rounding level the two precisions may pick different
+    # sides, and one flipped element moves a channel's weight gradient by O(1)
+    side = (ya.detach() > 0).double()
+    yb = pre * side if act == 1 else pre * (side + (1 - side) * 0.2) if act == 2 else pre
+    (ya * w).sum().backward()
+    (yb * w.double()).sum().backward()
+    keep = (pre.detach().abs() > 1e-5)
+    tol = lambda t: 1e-5 * max(1.0, t.abs().max().item())
+    assert ((ya.double() - yb).abs() * keep).max().item() < tol(yb)
+    assert ((xa.grad.double() - xb.grad).abs() * keep).max().item() < tol(xb.grad)
+    assert (bn_a.weight.grad.double() - bn_b.weight.grad).abs().max().item() < tol(bn_b.weight.grad)
+    assert (bn_a.bias.grad.double() - bn_b.bias.grad).abs().max().item() < tol(bn_b.bias.grad)
+    assert torch.allclose(bn_a.running_mean.double(), bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn_a.running_var.double(), bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == 1
