@@ -10,7 +10,9 @@
 //             bn_bwd_apply   gx = A g' + B x + C, coefficients inline from the sums              (2 reads, 1 write)  + grad weight / bias
 // The activation is folded into both directions (its mask is recomputed from a x + b), so the separate activation forward / backward
 // passes disappear as well.  Per-thread partial sums are fp32 over <= a few hundred values in four independent lanes, everything
-// above that (wave, workgroup, grid) is accumulated in double, and mean / variance / coefficients are formed in double.
+// above that (wave, workgroup, grid) is accumulated in double, and mean / variance / coefficients are formed in double.  The grid-level
+// step has no atomics and no memset: workgroup g of channel c stores its pair to sums[g][c], and the apply kernels add the G <= 32
+// pairs of their channel themselves (lane-parallel, a few hundred cycles per workgroup) -- deterministic, two launches per direction.
 // x f32[B, C, inner] contiguous, inner % 4 == 0.
 #include "gdm_common.h"
 #include <math.h>
@@ -26,7 +28,8 @@ __device__ __forceinline__ float act_mask(float pre, float g, int act, float slo
     return g;
 }
 
-// MODE 0: sums[c] = (sum x, sum x^2);  MODE 1: sums[c] = (sum g', sum g' x).  sums[2C] = number of elements per channel.
+// MODE 0: sums[g][c] = (sum x, sum x^2) of workgroup g's share;  MODE 1: (sum g', sum g' x).  sums[2CG] = number of elements per
+// channel, sums[2CG+1] = G.
 template <int MODE>
 __global__ __launch_bounds__(BN_T) void bn_reduce_kernel(const float4* __restrict__ x, const float4* __restrict__ go, const float* __restrict__ saved,
                                                          int C, unsigned inner4, unsigned total4, int act, float slope, double* __restrict__ sums)
@@ -81,24 +84,47 @@ __global__ __launch_bounds__(BN_T) void bn_reduce_kernel(const float4* __restric
             t0 += part[w][0];
             t1 += part[w][1];
         }
-        atomicAdd(&sums[2 * c], t0);
-        atomicAdd(&sums[2 * c + 1], t1);
-        if (blockIdx.x == 0 && c == 0) sums[2 * C] = (double)total4 * 4.0;
+        sums[((long)blockIdx.x * C + c) * 2] = t0;
+        sums[((long)blockIdx.x * C + c) * 2 + 1] = t1;
+        if (blockIdx.x == 0 && c == 0) {
+            sums[2L * C * gridDim.x] = (double)total4 * 4.0;
+            sums[2L * C * gridDim.x + 1] = (double)gridDim.x;
+        }
     }
+}
+
+// channel c's totals from the G partial pairs (every wave computes them redundantly; G <= 64)
+__device__ __forceinline__ void channel_sums(const double* __restrict__ sums, int C, int c, int G, double& t0, double& t1)
+{
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (lane < G) {
+        a = sums[((long)lane * C + c) * 2];
+        b = sums[((long)lane * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, 64);
+        b += __shfl_xor(b, m, 64);
+    }
+    t0 = a;
+    t1 = b;
 }
 
 // y = act(a x + b) with a = w rstd, b = bias - mean a from the (possibly all-reduced) sums; the b = 0 planes also store
 // saved = (a | b | mean | rstd) for the backward and update the running statistics (momentum m, unbiased variance).
 __global__ __launch_bounds__(BN_T) void bn_fwd_apply_kernel(const float4* __restrict__ x, const double* __restrict__ sums, const float* __restrict__ weight,
-                                                            const float* __restrict__ bias, int C, long inner4, float eps, float momentum,
+                                                            const float* __restrict__ bias, int C, int G, long inner4, float eps, float momentum,
                                                             int act, float slope, float* __restrict__ saved, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float4* __restrict__ y)
 {
     const long plane = blockIdx.y;
     const int c = (int)(plane % C);
-    const double n = sums[2 * C];
-    const double mean = sums[2 * c] / n;
-    const double var = fmax(sums[2 * c + 1] / n - mean * mean, 0.0);
+    const double n = sums[2L * C * G];
+    double t0, t1;
+    channel_sums(sums, C, c, G, t0, t1);
+    const double mean = t0 / n;
+    const double var = fmax(t1 / n - mean * mean, 0.0);
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const double ad = (double)weight[c] * rstd;
     const float a = (float)ad, b = (float)((double)bias[c] - mean * ad);
@@ -129,7 +155,7 @@ __global__ __launch_bounds__(BN_T) void bn_fwd_apply_kernel(const float4* __rest
 // gx = A g' + B x + Cc with S1 = sum g', S2 = rstd (sum g' x - mean S1):  A = w rstd,  B = -w rstd^2 S2 / n,  Cc = -B mean - w rstd S1 / n;
 // grad weight = S2, grad bias = S1 (stored by the b = 0 planes).
 __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ go, const double* __restrict__ sums,
-                                                            const float* __restrict__ weight, const float* __restrict__ saved, int C, long inner4,
+                                                            const float* __restrict__ weight, const float* __restrict__ saved, int C, int G, long inner4,
                                                             int act, float slope, float* __restrict__ gweight, float* __restrict__ gbias,
                                                             float4* __restrict__ gx)
 {
@@ -137,9 +163,10 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(const float4* __rest
     const int c = (int)(plane % C);
     const float a = saved[c], b = saved[C + c];
     const double mean = (double)saved[2 * C + c], rstd = (double)saved[3 * C + c];
-    const double n = sums[2 * C];
-    const double S1 = sums[2 * c];
-    const double S2 = rstd * (sums[2 * c + 1] - mean * S1);
+    const double n = sums[2L * C * G];
+    double S1, S2x;
+    channel_sums(sums, C, c, G, S1, S2x);
+    const double S2 = rstd * (S2x - mean * S1);
     const double wr = (double)weight[c] * rstd;
     const double Bd = -wr * rstd * S2 / n;
     const float A = (float)wr, Bc = (float)Bd, Cc = (float)(-Bd * mean - wr * S1 / n);
@@ -169,33 +196,45 @@ bool bn_shape_ok(const void* p0, const void* p1, const void* p2, int B, int C, l
            (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
 }
 
-dim3 reduce_grid(int B, int C, long inner)
+int reduce_groups(int B, int C, long inner)
 {
-    // ~2048 workgroups over the chip, at least ~8 float4 per thread
+    // ~2048 workgroups over the chip, at least ~8 float4 per thread, at most 32 partial pairs per channel
     const long total4 = (long)B * (inner / 4);
     long g = (2048 + C - 1) / C;
     const long gmax = (total4 + BN_T * 8 - 1) / (BN_T * 8);
     if (g > gmax) g = gmax;
+    if (g > 32) g = 32;
     if (g < 1) g = 1;
-    return dim3((unsigned)g, (unsigned)C);
+    return (int)g;
 }
 
 dim3 apply_grid(int B, int C, long inner)
 {
-    long gx = (inner / 4 + BN_T - 1) / BN_T;
+    // ~8 float4 per thread (the per-workgroup prologue forms the channel's coefficients in double), but no fewer than ~1024 workgroups
+    const long inner4 = inner / 4, planes = (long)B * C;
+    long gx = inner4 / (BN_T * 8);
+    if (gx * planes < 1024) gx = (1024 + planes - 1) / planes;
+    const long gmax = (inner4 + BN_T - 1) / BN_T;
+    if (gx > gmax) gx = gmax;
     if (gx > 64) gx = 64;
-    return dim3((unsigned)gx, (unsigned)(B * C));
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)planes);
 }
 
 } // namespace
+
+extern "C" long gdm_bn_sums_len(int B, int C, long inner)
+{
+    if (B < 1 || C < 1 || inner < 4) return 0;
+    return 2L * C * reduce_groups(B, C, inner) + 2;
+}
 
 extern "C" int gdm_bn_stats_hip(const float* x, int B, int C, long inner, double* sums, void* stream)
 {
     GDM_CHECK_ARG(x && sums, "gdm_bn_stats_hip: NULL pointer");
     GDM_CHECK_ARG(bn_shape_ok(x, nullptr, nullptr, B, C, inner), "gdm_bn_stats_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     hipStream_t s = (hipStream_t)stream;
-    GDM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)C + 1), s));
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, reduce_grid(B, C, inner), dim3(BN_T), 0, s, (const float4*)x, (const float4*)nullptr, (const float*)nullptr, C,
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(reduce_groups(B, C, inner), C), dim3(BN_T), 0, s, (const float4*)x, (const float4*)nullptr, (const float*)nullptr, C,
                        (unsigned)(inner / 4), (unsigned)((long)B * (inner / 4)), 0, 0.f, sums);
     return gdm_launch_status("bn_reduce_kernel<0>");
 }
@@ -208,8 +247,8 @@ extern "C" int gdm_bn_fwd_apply_hip(const float* x, const double* sums, const fl
     GDM_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "gdm_bn_fwd_apply_hip: running_mean and running_var go together");
     GDM_CHECK_ARG(bn_shape_ok(x, y, nullptr, B, C, inner), "gdm_bn_fwd_apply_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_bn_fwd_apply_hip: act=%d", act);
-    hipLaunchKernelGGL(bn_fwd_apply_kernel, apply_grid(B, C, inner), dim3(BN_T), 0, (hipStream_t)stream, (const float4*)x, sums, weight, bias, C, inner / 4,
-                       eps, momentum, act, slope, saved, running_mean, running_var, (float4*)y);
+    hipLaunchKernelGGL(bn_fwd_apply_kernel, apply_grid(B, C, inner), dim3(BN_T), 0, (hipStream_t)stream, (const float4*)x, sums, weight, bias, C,
+                       reduce_groups(B, C, inner), inner / 4, eps, momentum, act, slope, saved, running_mean, running_var, (float4*)y);
     return gdm_launch_status("bn_fwd_apply_kernel");
 }
 
@@ -220,8 +259,7 @@ extern "C" int gdm_bn_bwd_reduce_hip(const float* x, const float* grad_out, cons
     GDM_CHECK_ARG(bn_shape_ok(x, grad_out, nullptr, B, C, inner), "gdm_bn_bwd_reduce_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_bn_bwd_reduce_hip: act=%d", act);
     hipStream_t s = (hipStream_t)stream;
-    GDM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)C + 1), s));
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, reduce_grid(B, C, inner), dim3(BN_T), 0, s, (const float4*)x, (const float4*)grad_out, saved, C,
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(reduce_groups(B, C, inner), C), dim3(BN_T), 0, s, (const float4*)x, (const float4*)grad_out, saved, C,
                        (unsigned)(inner / 4), (unsigned)((long)B * (inner / 4)), act, slope, sums);
     return gdm_launch_status("bn_reduce_kernel<1>");
 }
@@ -233,6 +271,6 @@ extern "C" int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const
     GDM_CHECK_ARG(bn_shape_ok(x, grad_out, grad_x, B, C, inner), "gdm_bn_bwd_apply_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_bn_bwd_apply_hip: act=%d", act);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(B, C, inner), dim3(BN_T), 0, (hipStream_t)stream, (const float4*)x, (const float4*)grad_out, sums,
-                       weight, saved, C, inner / 4, act, slope, grad_weight, grad_bias, (float4*)grad_x);
+                       weight, saved, C, reduce_groups(B, C, inner), inner / 4, act, slope, grad_weight, grad_bias, (float4*)grad_x);
     return gdm_launch_status("bn_bwd_apply_kernel");
 }

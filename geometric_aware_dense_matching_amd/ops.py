@@ -385,7 +385,7 @@ class _BatchNormAct(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         inner = x.numel() // (B * C)
         L = _lib.lib()
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        sums = torch.empty(L.gdm_bn_sums_len(B, C, inner), dtype=torch.float64, device=x.device)
         saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         check(L.gdm_bn_stats_hip(x.data_ptr(), B, C, inner, sums.data_ptr(), _stream()), "gdm_bn_stats_hip")
@@ -403,7 +403,7 @@ class _BatchNormAct(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         inner = x.numel() // (B * C)
         L = _lib.lib()
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        sums = torch.empty(L.gdm_bn_sums_len(B, C, inner), dtype=torch.float64, device=x.device)
         gw = torch.empty(C, dtype=torch.float32, device=x.device)
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
         gx = torch.empty_like(x)
