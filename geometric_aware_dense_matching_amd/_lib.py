@@ -81,9 +81,9 @@ SIGNATURES = {
     "gdm_psp_pools_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gdm_bn_sums_len": (ctypes.c_long, [_i, _i, ctypes.c_long]),
     "gdm_bn_stats_hip": (_i, [_vp, _i, _i, ctypes.c_long, _vp, _vp]),
-    "gdm_bn_fwd_apply_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gdm_bn_fwd_apply_hip": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, ctypes.c_long, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "gdm_bn_bwd_reduce_hip": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_long, _i, _f, _vp, _vp]),
-    "gdm_bn_bwd_apply_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _i, _f, _vp, _vp, _vp, _vp]),
+    "gdm_bn_bwd_apply_hip": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, ctypes.c_long, _i, _f, _vp, _vp, _vp, _vp]),
     "gdm_psp_pools_bwd_hip": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _i, _vp, _vp]),
     "gdm_conv1x1_weight_bytes": (_sz, [_i, _i]),
     "gdm_conv1x1_pack_weight_hip": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -239,16 +239,17 @@ extern "C" int gdm_bn_stats_hip(const float* x, int B, int C, long inner, double
     return gdm_launch_status("bn_reduce_kernel<0>");
 }
 
-extern "C" int gdm_bn_fwd_apply_hip(const float* x, const double* sums, const float* weight, const float* bias, int B, int C, long inner, float eps,
-                                    float momentum, int act, float slope, float* saved, float* running_mean, float* running_var, float* y,
+extern "C" int gdm_bn_fwd_apply_hip(const float* x, const double* sums, int groups, const float* weight, const float* bias, int B, int C, long inner,
+                                    float eps, float momentum, int act, float slope, float* saved, float* running_mean, float* running_var, float* y,
                                     void* stream)
 {
     GDM_CHECK_ARG(x && sums && weight && bias && saved && y, "gdm_bn_fwd_apply_hip: NULL pointer");
     GDM_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "gdm_bn_fwd_apply_hip: running_mean and running_var go together");
     GDM_CHECK_ARG(bn_shape_ok(x, y, nullptr, B, C, inner), "gdm_bn_fwd_apply_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_bn_fwd_apply_hip: act=%d", act);
+    GDM_CHECK_ARG(groups >= 0 && groups <= 64, "gdm_bn_fwd_apply_hip: groups=%d not in [0,64]", groups);
     hipLaunchKernelGGL(bn_fwd_apply_kernel, apply_grid(B, C, inner), dim3(BN_T), 0, (hipStream_t)stream, (const float4*)x, sums, weight, bias, C,
-                       reduce_groups(B, C, inner), inner / 4, eps, momentum, act, slope, saved, running_mean, running_var, (float4*)y);
+                       groups ? groups : reduce_groups(B, C, inner), inner / 4, eps, momentum, act, slope, saved, running_mean, running_var, (float4*)y);
     return gdm_launch_status("bn_fwd_apply_kernel");
 }
 
@@ -264,13 +265,14 @@ extern "C" int gdm_bn_bwd_reduce_hip(const float* x, const float* grad_out, cons
     return gdm_launch_status("bn_reduce_kernel<1>");
 }
 
-extern "C" int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* sums, const float* weight, const float* saved, int B, int C,
-                                    long inner, int act, float slope, float* grad_weight, float* grad_bias, float* grad_x, void* stream)
+extern "C" int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* sums, int groups, const float* weight, const float* saved,
+                                    int B, int C, long inner, int act, float slope, float* grad_weight, float* grad_bias, float* grad_x, void* stream)
 {
     GDM_CHECK_ARG(x && grad_out && sums && weight && saved && grad_weight && grad_bias && grad_x, "gdm_bn_bwd_apply_hip: NULL pointer");
     GDM_CHECK_ARG(bn_shape_ok(x, grad_out, grad_x, B, C, inner), "gdm_bn_bwd_apply_hip: B=%d C=%d inner=%ld (inner %% 4 == 0, B*C <= 65535, 16-byte aligned)", B, C, inner);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_bn_bwd_apply_hip: act=%d", act);
+    GDM_CHECK_ARG(groups >= 0 && groups <= 64, "gdm_bn_bwd_apply_hip: groups=%d not in [0,64]", groups);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(B, C, inner), dim3(BN_T), 0, (hipStream_t)stream, (const float4*)x, (const float4*)grad_out, sums,
-                       weight, saved, C, reduce_groups(B, C, inner), inner / 4, act, slope, grad_weight, grad_bias, (float4*)grad_x);
+                       weight, saved, C, groups ? groups : reduce_groups(B, C, inner), inner / 4, act, slope, grad_weight, grad_bias, (float4*)grad_x);
     return gdm_launch_status("bn_bwd_apply_kernel");
 }

@@ -378,9 +378,22 @@ def affine_act(x, scale, shift, act=ACT_NONE, slope=0.0, res=None, res_scale=Non
     return y
 
 
+def _fold_and_all_reduce(sums, C, group):
+    """Partial pairs [G][C][2] + count + G  ->  double[2C+1] = one pair per channel + count, summed over the ranks of `group`."""
+    import torch.distributed as dist
+    compact = torch.cat([sums[:-2].view(-1, 2 * C).sum(0), sums[-2:-1]])
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(compact, group=group)
+    else:                                                   # gloo rehearsals: through host memory
+        host = compact.cpu()
+        dist.all_reduce(host, group=group)
+        compact = host.to(sums.device)
+    return compact
+
+
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, slope, group):
         x = _dev(x, torch.float32, "x")
         B, C = x.shape[0], x.shape[1]
         inner = x.numel() // (B * C)
@@ -389,11 +402,15 @@ class _BatchNormAct(torch.autograd.Function):
         saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         check(L.gdm_bn_stats_hip(x.data_ptr(), B, C, inner, sums.data_ptr(), _stream()), "gdm_bn_stats_hip")
-        check(L.gdm_bn_fwd_apply_hip(x.data_ptr(), sums.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, C, inner, float(eps), float(momentum),
-                                     act, float(slope), saved.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
+        groups = 0
+        if group is not None:                               # SyncBatchNorm: statistics over the whole data-parallel batch
+            sums, groups = _fold_and_all_reduce(sums, C, group), 1
+        check(L.gdm_bn_fwd_apply_hip(x.data_ptr(), sums.data_ptr(), groups, weight.data_ptr(), bias.data_ptr(), B, C, inner, float(eps),
+                                     float(momentum), act, float(slope), saved.data_ptr(),
+                                     running_mean.data_ptr() if running_mean is not None else None,
                                      running_var.data_ptr() if running_var is not None else None, y.data_ptr(), _stream()), "gdm_bn_fwd_apply_hip")
         ctx.save_for_backward(x, weight, saved)
-        ctx.act, ctx.slope = act, float(slope)
+        ctx.act, ctx.slope, ctx.group = act, float(slope), group
         return y
 
     @staticmethod
@@ -409,20 +426,44 @@ class _BatchNormAct(torch.autograd.Function):
         gx = torch.empty_like(x)
         check(L.gdm_bn_bwd_reduce_hip(x.data_ptr(), go.data_ptr(), saved.data_ptr(), B, C, inner, ctx.act, ctx.slope, sums.data_ptr(), _stream()),
               "gdm_bn_bwd_reduce_hip")
-        check(L.gdm_bn_bwd_apply_hip(x.data_ptr(), go.data_ptr(), sums.data_ptr(), weight.data_ptr(), saved.data_ptr(), B, C, inner, ctx.act, ctx.slope,
-                                     gw.data_ptr(), gb.data_ptr(), gx.data_ptr(), _stream()), "gdm_bn_bwd_apply_hip")
-        return gx, gw, gb, None, None, None, None, None, None
+        groups = 0
+        local = None
+        if ctx.group is not None:
+            # grad_x needs the sums over the whole batch; grad weight / bias stay LOCAL sums (DDP averages parameter gradients over
+            # the ranks afterwards, as with nn.SyncBatchNorm)
+            local = sums[:-2].view(-1, C, 2).sum(0)
+            sums, groups = _fold_and_all_reduce(sums, C, ctx.group), 1
+        check(L.gdm_bn_bwd_apply_hip(x.data_ptr(), go.data_ptr(), sums.data_ptr(), groups, weight.data_ptr(), saved.data_ptr(), B, C, inner,
+                                     ctx.act, ctx.slope, gw.data_ptr(), gb.data_ptr(), gx.data_ptr(), _stream()), "gdm_bn_bwd_apply_hip")
+        if local is not None:
+            mean, rstd = saved[2 * C:3 * C].double(), saved[3 * C:].double()
+            gb = local[:, 0].float()
+            gw = (rstd * (local[:, 1] - mean * local[:, 0])).float()
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 USE_FUSED_BN_TRAIN = __import__("os").environ.get("GDM_FUSED_BN_TRAIN", "1") != "0"
+# GDM_FUSED_SYNCBN=0 keeps nn.SyncBatchNorm modules on torch's implementation (A/B switch)
+USE_FUSED_SYNCBN = __import__("os").environ.get("GDM_FUSED_SYNCBN", "1") != "0"
+
+
+def _sync_group(bn):
+    """Process group of a SyncBatchNorm that actually spans several ranks, else None."""
+    import torch.distributed as dist
+    if not (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
 
 
 def bn_train_supported(x, bn):
-    """Plain (not Sync) affine BatchNorm in training mode with torch-style running statistics, on a contiguous f32 GPU map whose inner
-    size is a multiple of 4."""
+    """Affine BatchNorm{1,2}d -- or SyncBatchNorm -- in training mode with torch-style running statistics, on a contiguous f32 GPU map
+    whose inner size is a multiple of 4."""
     if not (USE_FUSED_BN_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous()):
         return False
-    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d) or not bn.affine or bn.momentum is None or not bn.track_running_stats:
+    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d) and not (USE_FUSED_SYNCBN and type(bn) is torch.nn.SyncBatchNorm):
+        return False
+    if not bn.affine or bn.momentum is None or not bn.track_running_stats:
         return False
     B, C = x.shape[0], x.shape[1]
     inner = x.numel() // max(B * C, 1)
@@ -430,9 +471,9 @@ def bn_train_supported(x, bn):
 
 
 def batch_norm_act_train(x, bn, act=ACT_NONE, slope=0.0):
-    """Training-mode `act(bn(x))` (batch statistics, running statistics updated as nn.BatchNorm does) with a fused backward.
-    act: ACT_NONE / ACT_RELU / ACT_LEAKY(slope).  Caller checks bn_train_supported."""
-    y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, slope)
+    """Training-mode `act(bn(x))` (batch statistics -- over all ranks for a SyncBatchNorm -- and running statistics updated as the
+    module does) with a fused backward.  act: ACT_NONE / ACT_RELU / ACT_LEAKY(slope).  Caller checks bn_train_supported."""
+    y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, slope, _sync_group(bn))
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return y

@@ -336,17 +336,18 @@ int gdm_depth_to_xyz_hip(const float* depth, const float* K, const int32_t* orig
  * (models/pytorch_utils.py:70-124, models/RandLA/pytorch_utils.py:34-105, models/cnn/extractors.py:36-58; train_lm.py:171-225).
  * x, y, grad f32[B,C,inner] contiguous (inner % 4 == 0, B*C <= 65535, 16-byte aligned).  sums: double[gdm_bn_sums_len(B,C,inner)] =
  * G partial pairs per channel of (sum x, sum x^2) -- or (sum g', sum g' x) in the backward, g' = grad * act'(.) -- then the element
- * count per channel and G; no atomics, no memset, the apply calls add the partials.  A data-parallel caller all-reduces the first
- * len-1 entries between the reduce and the apply call (SyncBatchNorm semantics).
+ * count per channel and G; no atomics, no memset, the apply calls add the partials (`groups` = 0: the layout the reduce call of the
+ * same shape wrote).  A data-parallel caller (SyncBatchNorm semantics, /root/reference/train_lm.py:412) folds the partials to one
+ * pair per channel, all-reduces pairs and count, and passes that buffer -- double[2C+1]: pairs, count -- with `groups` = 1.
  * saved f32[4C] = folded scale | folded shift | mean | rstd, written by the forward apply, read by both backward calls.
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  running_mean / running_var (both or neither) are updated with `momentum`. */
 long gdm_bn_sums_len(int B, int C, long inner);
 int gdm_bn_stats_hip(const float* x, int B, int C, long inner, double* sums, void* stream);
-int gdm_bn_fwd_apply_hip(const float* x, const double* sums, const float* weight, const float* bias, int B, int C, long inner, float eps,
+int gdm_bn_fwd_apply_hip(const float* x, const double* sums, int groups, const float* weight, const float* bias, int B, int C, long inner, float eps,
                          float momentum, int act, float slope, float* saved, float* running_mean, float* running_var, float* y, void* stream);
 int gdm_bn_bwd_reduce_hip(const float* x, const float* grad_out, const float* saved, int B, int C, long inner, int act, float slope,
                           double* sums, void* stream);
-int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* sums, const float* weight, const float* saved, int B, int C,
+int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* sums, int groups, const float* weight, const float* saved, int B, int C,
                          long inner, int act, float slope, float* grad_weight, float* grad_bias, float* grad_x, void* stream);
 
 #ifdef __cplusplus

@@ -253,3 +253,68 @@ def test_fused_batchnorm_act_training_matches_modules(shape, act):
     assert torch.allclose(bn_a.running_mean.double(), bn_b.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn_a.running_var.double(), bn_b.running_var, rtol=1e-5, atol=1e-6)
     assert int(bn_a.num_batches_tracked) == 1
+
+
+def _syncbn_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geometric_aware_dense_matching_amd import ops
+        torch.cuda.set_device(0)
+        torch.manual_seed(3)
+        B, C, H, W = 6, 8, 16, 24
+        x = torch.randn(B, C, H, W, device="cuda") * 1.5 + 0.3
+        w = torch.randn(B, C, H, W, device="cuda")
+        gamma, beta = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        # fp64 reference over the WHOLE batch
+        ref = torch.nn.BatchNorm2d(C).cuda().double().train()
+        with torch.no_grad():
+            ref.weight.copy_(gamma); ref.bias.copy_(beta)
+        xr = x.double().requires_grad_(True)
+        pre = ref(xr)
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        bn = torch.nn.SyncBatchNorm(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        xs = x[lo:hi].clone().requires_grad_(True)
+        assert ops.bn_train_supported(xs, bn) and ops._sync_group(bn) is not None
+        y = ops.batch_norm_act_train(xs, bn, ops.ACT_RELU)
+        (y * w[lo:hi]).sum().backward()
+        side = torch.zeros_like(pre)
+        sides = [torch.zeros(hi - lo, C, H, W, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(sides, (y.detach() > 0).double().cpu())
+        side = torch.cat(sides).cuda()
+        ((pre * side) * w.double()).sum().backward()
+        tol = lambda t: 1e-5 * max(1.0, t.abs().max().item())
+        assert (y.double() - (pre * side)[lo:hi]).abs().max().item() < tol(pre)
+        assert (xs.grad.double() - xr.grad[lo:hi]).abs().max().item() < tol(xr.grad)
+        gw, gb = bn.weight.grad.double().cpu(), bn.bias.grad.double().cpu()
+        dist.all_reduce(gw); dist.all_reduce(gb)                      # local sums -> whole batch (DDP would average them)
+        assert (gw.cuda() - ref.weight.grad).abs().max().item() < tol(ref.weight.grad)
+        assert (gb.cuda() - ref.bias.grad).abs().max().item() < tol(ref.bias.grad)
+        assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_var.double(), ref.running_var, rtol=1e-5, atol=1e-6)
+        if rank == 0:
+            out.put("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_syncbatchnorm_two_ranks_equals_whole_batch_batchnorm():
+    """SyncBatchNorm through the fused kernels: two ranks (gloo, both on this GPU) with half the batch each == fp64 BatchNorm + ReLU over
+    the whole batch -- outputs, input gradients, summed parameter gradients, running statistics."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert out.get() == "ok"
