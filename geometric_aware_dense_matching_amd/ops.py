@@ -537,7 +537,7 @@ class _UpconvGather(torch.autograd.Function):
         gz = torch.empty((B, 9 * cout, H, W), dtype=torch.float32, device=go.device)
         check(_lib.lib().gdm_upconv3x3_gather_bwd_hip(go.data_ptr(), B, cout, H, W, OH, OW, gz.data_ptr(), _stream()),
               "gdm_upconv3x3_gather_bwd_hip")
-        return gz, (go.sum(dim=(0, 2, 3)) if ctx.has_bias else None), None, None, None
+        return gz, (channel_sum(go) if ctx.has_bias else None), None, None, None
 
 
 def upconv3x3_gather_train(z, bias, cout, out_size):
@@ -643,6 +643,20 @@ def conv1x1_logsoftmax(x, weight, bias):
     return out
 
 
+def channel_sum(t):
+    """t f32[B,C,...] -> f32[C] sums over batch and inner dimensions (bias gradients): the streaming reduction of the BatchNorm kernels
+    (fp32 lanes, double above) where its shape rules hold -- torch's generic reduce_kernel moves these maps at 0.7 TB/s."""
+    B, C = t.shape[0], t.shape[1]
+    inner = t.numel() // max(B * C, 1)
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and B * C <= 65535 and inner >= 4 and inner % 4 == 0
+            and t.data_ptr() % 16 == 0):
+        return t.sum(dim=[0] + list(range(2, t.dim())))
+    L = _lib.lib()
+    sums = torch.empty(L.gdm_bn_sums_len(B, C, inner), dtype=torch.float64, device=t.device)
+    check(L.gdm_bn_stats_hip(t.data_ptr(), B, C, inner, sums.data_ptr(), _stream()), "gdm_bn_stats_hip")
+    return sums[:-2].view(-1, C, 2)[:, :, 0].sum(0).float()
+
+
 class _PspPools(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -702,7 +716,7 @@ class _PspCombine(torch.autograd.Function):
             gy = torch.empty((B, C, s_, s_), dtype=torch.float32, device=go.device)
             check(L.gdm_upsample_bilinear_bwd_hip(gpre.data_ptr(), B * C, s_, s_, H, W, gy.data_ptr(), _stream()), "gdm_upsample_bilinear_bwd_hip")
             gys.append(gy)
-        gb = gpre.sum((0, 2, 3)) if ctx.has_bias else None
+        gb = channel_sum(gpre) if ctx.has_bias else None
         return gpre, gb, gys[0], gys[1], gys[2], gys[3]
 
 
