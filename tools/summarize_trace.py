@@ -3,8 +3,8 @@
 
 bench.py's warmup runs MIOpen's find mode (hundreds of trial kernels), so whole-process --stats are
 dominated by it.  This tool cuts the trace to the TIMED steps: a step starts at its knn_kernel<1>
-launch; the window is the last `--steps` steps before the roofline loop (the first run of
-match_kernel<.., true> launches).  Usage:
+launch; the window is the `--steps` timed steps (the instrumented stage-timing steps and the forward in front of the roofline
+loop, which follow them, are left out).  Usage:
     python tools/summarize_trace.py gpurun_out/prof/*_kernel_trace.csv --steps 10 > profiles/rNN_steady.csv
 """
 import argparse
@@ -32,8 +32,9 @@ def main():
         s, e = starts[-(a.steps + 1)], starts[-1]
     else:
         starts = [i for i, r in enumerate(rows) if "knn_kernel<1>" in r["Kernel_Name"]]
-        # steps: warmup W, timed K, then one more forward before the roofline loop
-        s, e = starts[-(a.steps + 1)], starts[-1]
+        # steps: warmup W, timed K, min(K, 5) instrumented steps (stage events), then one more forward before the roofline loop
+        extra = min(a.steps, 5)
+        s, e = starts[-(a.steps + 1 + extra)], starts[-(1 + extra)]
     win = rows[s:e]
     t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
     agg = collections.OrderedDict()
@@ -54,7 +55,7 @@ def main():
         w.writerow([k, "%.1f" % (v[1] / a.steps), "%.4f" % (v[0] / 1e6 / a.steps), "%.2f" % (v[0] / v[1] / 1e3),
                     "%.2f" % (v[2] / 1e3), "%.2f" % (v[3] / 1e3), "%.2f" % (100.0 * v[0] / busy)])
     # roofline loop kernels (after the window)
-    tail = rows[e:]
+    tail = rows[starts[-1]:] if not a.periodic else rows[e:]
     for name in ("match_pipe_sim_kernel", "match_panel_kernel<0, true>", "match_panel_kernel<1, true>", "match_kernel<0, true>", "match_kernel<1, true>"):
         ds = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail if name in r["Kernel_Name"]]
         if ds:
