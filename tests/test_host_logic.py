@@ -85,3 +85,66 @@ def test_dgcnn_variant_state_dict_equals_the_reference():
     assert got == want
     g = np.load(os.path.join(G, "dgcnn_eval.npz"))
     assert np.allclose(m.model_emb.mesh.numpy(), g["mesh_buffer"], atol=1e-6)     # load_mesh arithmetic (dgcnn.py:188-202)
+
+
+def test_training_branch_of_conv_bn_act_blocks_on_cpu_equals_the_module_chain():
+    """The training branch that hands GPU maps to the fused BatchNorm kernels must be the plain module chain everywhere else
+    (CPU tensors here): same output, same gradients, same running statistics, for both block flavours."""
+    from geometric_aware_dense_matching_amd import layers
+    for make in (lambda: layers.pt_conv2d(6, 8, bn=True), lambda: layers.rl_conv2d(6, 8, bn=True),
+                 lambda: layers.rl_conv1d(6, 8, bn=True, activation=None), lambda: layers.pt_conv1d(6, 8, bn=False)):
+        torch.manual_seed(0)
+        a = make().train()
+        torch.manual_seed(0)
+        b = make().train()
+        shape = (3, 6, 5, 4) if isinstance(a.conv, torch.nn.Conv2d) else (3, 6, 20)
+        x = torch.randn(*shape)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya = a(xa)
+        yb = torch.nn.Sequential.forward(b, xb)
+        ya.square().sum().backward()
+        yb.square().sum().backward()
+        assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+        for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
+
+
+def test_fused_batchnorm_gate_and_host_helpers():
+    from geometric_aware_dense_matching_amd import ops
+    bn = torch.nn.BatchNorm2d(4).train()
+    assert not ops.bn_train_supported(torch.randn(2, 4, 8, 8), bn)            # CPU tensors never take the kernel path
+    assert ops._sync_group(bn) is None and ops._sync_group(torch.nn.SyncBatchNorm(4)) is None   # no process group here
+    t = torch.randn(3, 5, 4, 6)
+    assert torch.allclose(ops.channel_sum(t), t.sum((0, 2, 3)))
+    w, x = torch.randn(7, 5), torch.randn(3, 5, 11)
+    assert torch.allclose(ops.wx(w, x), torch.matmul(w, x), rtol=1e-5, atol=1e-6)
+    assert ops.psp_pools_supported(32, 32) and not ops.psp_pools_supported(4, 4) and not ops.psp_pools_supported(128, 128)
+
+
+def test_summarize_trace_windows(tmp_path):
+    """tools/summarize_trace.py: the bench window leaves out the instrumented steps and the forward in front of the roofline loop; the
+    training window is delimited by a kernel seen exactly once per step."""
+    import csv
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def write(path, names):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+            for i, n in enumerate(names):
+                w.writerow([n, 1000 * i, 1000 * i + 500])
+
+    step = ["void knn_kernel<1>(KnnTable)", "conv", "match_pipe_kernel"]
+    bench = step * 2 + step * 4 + step * 4 + step + ["match_pipe_sim_kernel"] * 3        # warmup 2, timed 4, instrumented 4, 1 forward
+    write(tmp_path / "b.csv", bench)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), str(tmp_path / "b.csv"), "--steps", "4"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "4 steps" in out.splitlines()[0] and "3 kernels/step" in out.splitlines()[0]
+    assert "match_pipe_sim_kernel calls=3" in out
+    train = ["find_a", "find_b"] + ["fwd", "loss_once", "bwd", "adam", "adam"] * 8        # 3 warmup + 5 timed
+    write(tmp_path / "t.csv", train)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), str(tmp_path / "t.csv"), "--steps", "5",
+                          "--periodic"], capture_output=True, text=True, check=True).stdout
+    assert "5 steps" in out.splitlines()[0] and "5 kernels/step" in out.splitlines()[0]
