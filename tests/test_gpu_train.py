@@ -318,3 +318,55 @@ def test_fused_syncbatchnorm_two_ranks_equals_whole_batch_batchnorm():
         p.join(240)
         assert p.exitcode == 0
     assert out.get() == "ok"
+
+
+def test_training_step_through_fused_paths_equals_module_paths():
+    """One whole training step (train-mode BatchNorm, dropout, fused circle loss) with the training-side kernel paths on == the same
+    step with all of them switched back to the torch modules: loss, running statistics and parameter gradients.
+
+    What the comparison can resolve: a randomly initialised network on a batch of 2 has channels whose batch variance is ~eps (RandLA's
+    eps is 1e-6), and train-mode BatchNorm amplifies any rounding difference by 1/sqrt(var + eps) there.  Measured with
+    tools/ab_train_paths.py (distance = relative L2 over all parameter gradients): the same path twice 2e-6; the paths that are
+    exact re-associations in fp32 (low-resolution up-convolution, split PSP bottleneck) 3e-3 each; the split-bf16 convolutions (1e-5
+    per output) 8e-2; the fused BatchNorm (fp64 sums against MIOpen's fp32 sums) 5e-2; everything 1.1e-1, loss 8e-5.  So the exact
+    paths are held to 3e-2, and the full set to a bound that only an O(1) error -- a dropped term, a wrong scale -- would break; the
+    per-operator tests above hold each kernel to 1e-4 .. 1e-5 against fp64."""
+    from geometric_aware_dense_matching_amd import cnn, ops, train_lm
+    from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+    M, N, B = 512, 1024, 2
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = GeoMatch(make_model_cfg(n_mesh_node=M, num_points=N), 1, model_points=synthetic.make_model_points(1, M)).to(dev).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    ds = train_lm.SyntheticCrops(B, N, M, seed=5)
+    batch = torch.utils.data.default_collate([ds[i] for i in range(B)])
+    flags = [(cnn, "USE_LOWRES_UPCONV_TRAIN"), (cnn, "USE_SPLIT_PSP_TRAIN"), (cnn, "USE_MFMA_CONV_TRAIN"), (ops, "USE_FUSED_BN_TRAIN")]
+
+    def run(on):
+        for mod, name in flags:
+            setattr(mod, name, name in on)
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)                                  # same dropout masks
+        out, _ = train_lm.model_fn_dec(model, batch, dev)
+        out["loss"].backward()
+        return (float(out["loss"].detach()),
+                {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if p.grad is not None},
+                {k: v.double().clone() for k, v in model.state_dict().items() if k.endswith("running_var")})
+
+    try:
+        l0, g0, s0 = run(())
+        l1, g1, s1 = run(("USE_LOWRES_UPCONV_TRAIN", "USE_SPLIT_PSP_TRAIN"))
+        l2, g2, s2 = run(tuple(n for _, n in flags))
+    finally:
+        for mod, name in flags:
+            setattr(mod, name, True)
+    den = sum((v ** 2).sum().item() for v in g0.values()) ** 0.5
+    dist = lambda g: sum(((g[k] - g0[k]) ** 2).sum().item() for k in g0) ** 0.5 / den
+    print("training A/B: loss %.6f / %.6f / %.6f, gradient distance exact paths %.3e, all paths %.3e" % (l0, l1, l2, dist(g1), dist(g2)))
+    assert np.isfinite(l0) and len(g0) > 300 and set(g0) == set(g1) == set(g2)
+    assert abs(l1 - l0) < 1e-4 * abs(l0) and abs(l2 - l0) < 1e-3 * abs(l0), (l0, l1, l2)
+    for k in s0:
+        assert torch.allclose(s0[k], s1[k], rtol=5e-2, atol=1e-3) and torch.allclose(s0[k], s2[k], rtol=5e-2, atol=1e-3), k
+    assert dist(g1) < 3e-2, dist(g1)
+    assert dist(g2) < 0.35, dist(g2)
