@@ -31,6 +31,8 @@ SIGNATURES = {
     "gdm_knn_batch": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
     "gdm_knn_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_knn_jobs_hip": (_i, [ctypes.POINTER(KnnJob), _i, _i, _vp]),
+    "gdm_knn_jobs_workspace_bytes": (_sz, [ctypes.POINTER(KnnJob), _i, _i]),
+    "gdm_knn_jobs_ws_hip": (_i, [ctypes.POINTER(KnnJob), _i, _i, _vp, _sz, _vp]),
     "gdm_ballquery_hip": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "gdm_furthestsampling_hip": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "gdm_group_gather_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -857,11 +857,13 @@ __global__ __launch_bounds__(256) void depth_to_xyz_kernel(const float* __restri
     if (u >= 0 && u < W && v >= 0 && v < H) d = depth[((long)b * H + v) * W + u];
     const float* k = K + b * 9;
     const float fx = k[0], cx = k[2], fy = k[4], cy = k[5];
-    const float m = d > 1e-8f ? 1.f : 0.f;
+    // dpt_2_pcld forms these in float64 (int64 pixel maps minus a float32 intrinsic promote to double in numpy) and the loader
+    // rounds to float32 once, at the end (linemod_pbr.py:398-411,573): same here, so the crop is bit-identical to the reference's.
+    const double m = d > 1e-8f ? 1.0 : 0.0;
     float* o = out + ((long)b * S * S + i) * 3;
-    o[0] = __fmul_rn(__fdiv_rn(__fmul_rn(__fsub_rn((float)u, cx), d), fx), m);
-    o[1] = __fmul_rn(__fdiv_rn(__fmul_rn(__fsub_rn((float)v, cy), d), fy), m);
-    o[2] = __fmul_rn(d, m);
+    o[0] = (float)(((double)u - (double)cx) * (double)d / (double)fx * m);
+    o[1] = (float)(((double)v - (double)cy) * (double)d / (double)fy * m);
+    o[2] = (float)((double)d * m);
 }
 
 inline float scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

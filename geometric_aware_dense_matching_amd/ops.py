@@ -90,8 +90,17 @@ def knn_jobs(jobs, B):
         arr[i].S, arr[i].Q, arr[i].K = S, Q, K
         outs.append(out)
         keep.append((sup, qry))
-    check(_lib.lib().gdm_knn_jobs_hip(arr, n, B, _stream()), "gdm_knn_jobs_hip")
+    _knn_launch(arr, n, B, jobs[0][0].device)
     return outs
+
+
+def _knn_launch(arr, n, B, device):
+    """gdm_knn_jobs_ws_hip with a workspace from torch's caching allocator (graph-capture safe): the K > 1 jobs' support sets are
+    re-laid out once per launch as hashed float4 tiles."""
+    L = _lib.lib()
+    nbytes = int(L.gdm_knn_jobs_workspace_bytes(arr, n, B))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    check(L.gdm_knn_jobs_ws_hip(arr, n, B, ws.data_ptr(), nbytes, _stream()), "gdm_knn_jobs_ws_hip")
 
 
 def ballquery(radius, nsample, xyz, new_xyz):

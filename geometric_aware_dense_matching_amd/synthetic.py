@@ -51,13 +51,17 @@ def make_frame(rs, hole_frac=0.05):
 
 
 def depth_to_xyz(depth, K=LM_K):
+    """`dpt_2_pcld` arithmetic (linemod_pbr.py:398-411): integer pixel maps minus a float32 intrinsic promote to
+    float64, so the reference forms x, y in double from the float32 depth and rounds to float32 once, at the end."""
     H, W = depth.shape
-    v, u = np.mgrid[:H, :W].astype(np.float32)
-    x = (u - K[0, 2]) * depth / K[0, 0]
-    y = (v - K[1, 2]) * depth / K[1, 1]
-    xyz = np.stack([x, y, depth], axis=2).astype(np.float32)
-    xyz *= (depth > 1e-8).astype(np.float32)[:, :, None]
-    return xyz
+    v, u = np.mgrid[:H, :W]
+    d = depth.astype(np.float32)
+    K = np.asarray(K, dtype=np.float32)
+    msk = (d > 1e-8).astype(np.float32)
+    x = (u - K[0][2]) * d / K[0][0]
+    y = (v - K[1][2]) * d / K[1][1]
+    xyz = np.stack([x, y, d.astype(np.float64)], axis=2) * msk[:, :, None]
+    return xyz.astype(np.float32)
 
 
 def make_crop(seed, n_points, S=256, duplicates=False):

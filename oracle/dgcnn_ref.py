@@ -43,6 +43,33 @@ def trunk(x, s, k):
     return F.conv1d(y, s["conv9.weight"])
 
 
+def trunk_graphs(x, s, k):
+    """The three dynamic graphs of one trunk: [(idx [B,n,k], pairwise_distance [B,n,n])] for xyz, x1, x2 (dgcnn.py:108-120)."""
+    out = [knn(x[:, :3], k)]
+    x1 = _cbl(_cbl(get_graph_feature(x, k, dim9=True), s, 1), s, 2).max(dim=-1)[0]
+    out.append(knn(x1, k))
+    x2 = _cbl(_cbl(get_graph_feature(x1, k), s, 3), s, 4).max(dim=-1)[0]
+    out.append(knn(x2, k))
+    return out
+
+
+def graph_mismatch_not_near_tie(idx, want, dist, tol):
+    """Rows whose neighbour SET differs from `want` although the differing candidates are NOT within `tol` (relative to the
+    row's k-th score) of each other: 0 means every disagreement is an fp32 near-tie at the k-th place."""
+    bad = 0
+    a, b = torch.sort(idx, dim=-1)[0], torch.sort(want, dim=-1)[0]
+    rows = torch.nonzero((a != b).any(dim=-1))
+    for bi, ri in rows.tolist():
+        sa, sb = set(idx[bi, ri].tolist()), set(want[bi, ri].tolist())
+        d = dist[bi, ri]
+        only = torch.tensor(sorted(sa ^ sb))
+        spread = (d[only].max() - d[only].min()).abs().item()
+        scale = max(1.0, d[idx[bi, ri]].abs().max().item())
+        if spread > tol * scale:
+            bad += 1
+    return bad
+
+
 def geomatch_dgcnn_forward(sd, cld_rgb_nrm, k_cloud=16, k_mesh=20):
     emb = trunk(cld_rgb_nrm, SD(sd, "pcd_emb."), k_cloud)
     mesh = trunk(sd["model_emb.mesh"], SD(sd, "model_emb."), k_mesh)

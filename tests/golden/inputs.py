@@ -31,6 +31,26 @@ def loss_inputs(M=512, Bl=2, Nl=256, seed=11):
     return d
 
 
+def sym_loss_inputs(M=512, Bl=2, seed=23):
+    """Symmetric-object training matching (geoMatch.py:86-100): the reference indexes the per-vertex symmetry table with POINT
+    indices and the per-point match table with its values, so the fixture keeps N == M (as the reference's default 4096/4096)."""
+    rs = np.random.RandomState(seed)
+    Nl = M
+    perm = rs.permutation(M)
+    sys_idx = np.arange(M)
+    for a, b in zip(perm[0::2], perm[1::2]):          # an involution, like a 180-degree symmetry
+        sys_idx[a], sys_idx[b] = b, a
+    labels = (rs.rand(Bl, Nl) < 0.55).astype(np.int64)
+    return dict(
+        rgbd_f=rs.randn(Bl, 128, Nl).astype(np.float32),
+        mesh_f=rs.randn(1, 128, M).astype(np.float32),
+        labels=labels,
+        match_idx=rs.randint(0, M + 1, size=(Bl, Nl)).astype(np.int64),
+        vis=(rs.rand(Bl, M) < 0.5).astype(np.float32),
+        sys_idx=sys_idx.astype(np.int64),
+    )
+
+
 def block_inputs(B=2, n=128, K=16, seed=7):
     rs = np.random.RandomState(seed)
     return dict(

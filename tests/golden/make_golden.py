@@ -6,8 +6,14 @@ nothing here travels to the GPU box except the .npz/.json it writes.  The refere
 tests, fixtures or known-answer vectors of its own, so every vector is
 produced by importing / compiling the reference's code here:
 
-  knn_pyramid_c1.npz     the 30 pyramid arrays of datasets/lm/linemod_pbr.py:515-569 at C1 size,
-                         every kNN call answered by the compiled reference nanoflann (oracle/_ref)
+  knn_pyramid_c1.npz     the 30 pyramid arrays at C1 size: the reference loader's OWN statements
+                         (datasets/lm/linemod_pbr.py:515-569, read from the mounted tree and executed here) with every
+                         kNN call answered by the compiled reference nanoflann (oracle/_ref)
+  frontend.npz           `dpt_2_pcld` (linemod_pbr.py:398-411) + the strided `sr2dptxyz` grids (:515-527) of the reference,
+                         executed from the mounted tree on a synthetic frame: SHA-256 of the float32 crop / grids + samples
+  geomatch_eval_c2.npz   reference GeoMatch.forward (eval) at the HEADLINE shape (N=2048, M=8192, batch 2) + the evaluator's
+                         matching lines (evaluator.py:79-93) applied to its outputs
+  losses_sym.npz         reference training matching loss for a SYMMETRIC object (matching_loss_sys, geoMatch.py:86-100)
   knn_dup.npz            a duplicate-point cloud: reference indices + their fp32 d2
   ops_blocks.npz         reference Dilated_res_block / Building_block / Att_pooling /
                          random_sample / nearest_interpolation / relative_pos_encoding outputs
@@ -15,7 +21,7 @@ produced by importing / compiling the reference's code here:
   geomatch_state.json    reference state_dict key names and shapes
   losses.npz             reference CircleLoss / FocalLoss / AutomaticWeightedLoss /
                          pointwise_feature_matching (training matching path) values and grads
-  matching.npz           evaluator.py:79-93 executed from the reference's own source text
+  matching.npz           evaluator.py:79-93 executed from the mounted reference tree
 
 Reference modules are imported with empty stand-in modules for third-party packages that are
 absent here and unused on this path (cv2, normalSpeed, plyfile, torch_geometric, ...).  The
@@ -108,6 +114,45 @@ def sample_entries(t, n, seed):
     return pos, flat[torch.from_numpy(pos)].numpy()
 
 
+def method_text(path, name, indent="    "):
+    """Source text of method/function `name` read from the mounted reference tree (never stored)."""
+    src = open(os.path.join(REF, path)).read().split("\n")
+    a0 = next(i for i, l in enumerate(src) if l.startswith(indent + "def " + name + "("))
+    a1 = next(i for i in range(a0 + 1, len(src)) if src[i].startswith(indent + "def ") or (src[i].strip() and not src[i].startswith(indent)))
+    import textwrap
+    return textwrap.dedent("\n".join(src[a0:a1]))
+
+
+def loader_pyramid_lines():
+    """Statements linemod_pbr.py:515-569 (xyz_lst ... up-sample stage) of LMDataset.get_item, dedented."""
+    import textwrap
+    src = open(os.path.join(REF, "datasets", "lm", "linemod_pbr.py")).read().split("\n")
+    a0 = next(i for i, l in enumerate(src) if l.strip().startswith("xyz_lst = [dpt_xyz_clip.transpose(2, 0, 1)]"))
+    a1 = next(i for i in range(a0, len(src)) if src[i].strip().startswith("item_dict = dict("))
+    return textwrap.dedent("\n".join(l for l in src[a0:a1] if l.strip()))
+
+
+def reference_pyramid(cld, dpt_xyz_clip, DP, in_size=256):
+    """Run the loader's own pyramid statements on (cld [N,3], dpt_xyz_clip [S,S,3]) -> its `inputs` dict."""
+    env = dict(np=np, DP=DP, self=types.SimpleNamespace(in_size=in_size), cld=cld.copy(), dpt_xyz_clip=dpt_xyz_clip.copy())
+    exec(loader_pyramid_lines(), env)
+    return env["inputs"], env["sr2dptxyz"]
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def evaluator_statements():
+    """The matching statements of cal_frame_poses (evaluator.py:79-93), read from the mounted tree; never stored."""
+    ev = open(os.path.join(REF, "evaluator.py")).read().split("\n")
+    i0 = next(i for i, l in enumerate(ev) if "seg_res = torch.argmax(seg_features,dim=0)" in l)
+    i1 = next(i for i, l in enumerate(ev) if "max_th, obj_pts_idx = torch.max(obj_pts_sim,dim=1)" in l)
+    return [l.strip() for l in ev[i0:i1 + 1]
+            if l.strip() and "return" not in l and "cpu().numpy()" not in l and not l.strip().startswith("if ")]
+
+
 def to_inputs(batch, pyr_list):
     """numpy batch + per-item pyramids -> reference input dict (model_fn_dec dtype rules, train_lm.py:158-172)."""
     inputs = {}
@@ -132,13 +177,36 @@ def main():
     torch.set_num_threads(8)
 
     # ------------------------------------------------------------------ kNN pyramid, C1 size
+    from helper_tool import DataProcessing as DP
     N1 = 1024
     crop = synthetic.make_crop(seed=101, n_points=N1)
     cld = crop["cld_rgb_nrm"][:3].T.copy()
-    pyr = opyr.build_pyramid(cld, crop["dpt_xyz"], knn_search=opyr.ref_knn_search)
+    pyr, _ = reference_pyramid(cld, crop["dpt_xyz"], DP)
+    mine = opyr.build_pyramid(cld, crop["dpt_xyz"], knn_search=opyr.ref_knn_search)
+    assert set(pyr) == set(mine) and all(np.array_equal(pyr[k], mine[k]) for k in pyr), "oracle pyramid != loader statements"
     np.savez_compressed(os.path.join(HERE, "knn_pyramid_c1.npz"),
                         **{k: v for k, v in pyr.items() if v.dtype != np.float32},
                         cld_checksum=np.float64(cld.astype(np.float64).sum()))
+
+    # ------------------------------------------------------------------ front end: dpt_2_pcld + strided grids
+    env = dict(np=np)
+    exec(method_text("datasets/lm/linemod_pbr.py", "dpt_2_pcld"), env)
+    rs = np.random.RandomState(77)
+    depth, _rgb, _nrm = synthetic.make_frame(rs)
+    xyz_full = env["dpt_2_pcld"](None, depth, 1, synthetic.LM_K)            # float64, as in the loader
+    fe = {}
+    for tag, (x0, y0) in (("a", (192, 112)), ("b", (37, 5))):
+        clip = xyz_full[y0:y0 + 256, x0:x0 + 256]                          # integer crop (warpAffine resampling is out of scope)
+        clip32 = clip.astype(np.float32)                                   # the loader's casts: knn.pyx:95-96, linemod_pbr.py:573
+        _, sr2 = reference_pyramid(np.zeros((1024, 3), np.float32) + clip32.reshape(-1, 3)[:1024], clip32,
+                                   types.SimpleNamespace(knn_search=lambda s, q, k: np.zeros((1, q.shape[1], k), np.int64)))
+        pos = np.random.RandomState(5).randint(0, clip32.size, size=2048)
+        fe.update({"origin_" + tag: np.array([x0, y0], np.int32), "xyz_sha_" + tag: np.array(sha(clip32)),
+                   "xyz_pos_" + tag: pos, "xyz_val_" + tag: clip32.reshape(-1)[pos]})
+        for sc, g in sr2.items():
+            fe["grid%d_sha_%s" % (sc, tag)] = np.array(sha(g.astype(np.float32)))
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **fe)
+
     dup = synthetic.make_crop(seed=202, n_points=N1, duplicates=True)
     dcld = dup["cld_rgb_nrm"][:3].T.copy()
     ridx = oknn.ref_knn_batch(dcld[None], dcld[None], 16)[0]
@@ -218,6 +286,50 @@ def main():
     g["mesh_features"] = model.model_emb.fixed_features.numpy()
     np.savez_compressed(os.path.join(HERE, "geomatch_eval.npz"), **g)
 
+    # ------------------------------------------------------------------ headline shape: N=2048, M=8192 (BASELINE configs[1]), batch 2
+    M2, B2, N2 = 8192, 2, 2048
+    mcfg2 = dict(cfg.MODEL)
+    mcfg2["n_mesh_node"] = M2
+    model2 = GM.GeoMatch(mcfg2, 1)
+    model2.load_state_dict(synthetic.synthetic_state_dict(model2.state_dict(), seed=0))
+    with torch.no_grad():     # 4 MB of mesh descriptors are not stored: tests regenerate them from the same seeded stream
+        model2.model_emb.fixed_features.copy_(torch.from_numpy(np.random.RandomState(1234).randn(128, M2).astype(np.float32)))
+    model2.eval()
+    batch2 = synthetic.make_batch(seed=21, batch=B2, n_points=N2)
+    pyrs2 = [reference_pyramid(batch2["cld_rgb_nrm"][i, :3].T.copy(), batch2["dpt_xyz"][i], DP)[0] for i in range(B2)]
+    inputs2 = to_inputs(batch2, pyrs2)
+    with torch.no_grad():
+        ep2 = model2(inputs2)
+        emb2 = model2.pcd_emb(inputs2)
+    g2 = {}
+    for name, t in (("seg", ep2["seg"]), ("rgbd", ep2["rgbd"]), ("emb", emb2)):
+        pos, val = sample_entries(t, 8192, seed=len(name) + 7)
+        g2[name + "_pos"], g2[name + "_val"] = pos, val
+        g2[name + "_norm"] = np.float64(t.double().norm().item())
+        g2[name + "_shape"] = np.array(t.shape)
+    for key in ("cld_nei_idx0", "r2p_ds_nei_idx0", "p2r_up_nei_idx2", "cld_interp_idx1"):      # a few pyramid arrays at this size
+        g2["pyr_" + key] = np.stack([p[key] for p in pyrs2]).astype(np.int32)
+    # evaluator.py:79-93 on the reference's own outputs (mesh descriptors = the stand-in's fixed features, regenerated by seed
+    # in the tests): arg-max index, max similarity, the selected-point mask and the similarity AT the arg-max's runner-up
+    ev_stmts = evaluator_statements()
+    g2["match_idx"], g2["match_val"], g2["match_msk"], g2["match_gap"] = [], [], [], []
+    for b in range(B2):
+        env = dict(torch=torch, F=torch.nn.functional, seg_features=ep2["seg"][b], rgbd_features=ep2["rgbd"][b],
+                   mesh_features=ep2["mesh"][0], cld=inputs2["cld_rgb_nrm"][b])
+        exec("\n".join(ev_stmts), env)
+        full_idx = np.full(N2, -1, np.int32)
+        full_val = np.zeros(N2, np.float32)
+        full_gap = np.zeros(N2, np.float32)
+        m = env["cls_msk"].numpy().astype(bool)
+        top2 = env["obj_pts_sim"].topk(2, dim=1)[0]
+        full_idx[m] = env["obj_pts_idx"].numpy()
+        full_val[m] = env["max_th"].numpy()
+        full_gap[m] = (top2[:, 0] - top2[:, 1]).numpy()
+        g2["match_idx"].append(full_idx); g2["match_val"].append(full_val); g2["match_msk"].append(m); g2["match_gap"].append(full_gap)
+    for k in ("match_idx", "match_val", "match_msk", "match_gap"):
+        g2[k] = np.stack(g2[k])
+    np.savez_compressed(os.path.join(HERE, "geomatch_eval_c2.npz"), **g2)
+
     # ------------------------------------------------------------------ losses / training matching
     Bl, Nl = 2, 256
     li = gin.loss_inputs(M, Bl, Nl)
@@ -246,16 +358,25 @@ def main():
         awl_params=model.awl.params.detach().numpy(), awl_total=total.item(),
         circle_loss=cl.item(), circle_grad=sim.grad.numpy())
 
-    # ------------------------------------------------------------------ inference matching, from the reference's own text
-    ev = open(os.path.join(REF, "evaluator.py")).read().split("\n")
-    i0 = next(i for i, l in enumerate(ev) if "seg_res = torch.argmax(seg_features,dim=0)" in l)
-    i1 = next(i for i, l in enumerate(ev) if "max_th, obj_pts_idx = torch.max(obj_pts_sim,dim=1)" in l)
-    stmts = [l.strip() for l in ev[i0:i1 + 1]
-             if l.strip() and "return" not in l and "cpu().numpy()" not in l and not l.strip().startswith("if ")]
+    # ------------------------------------------------------------------ symmetric object: matching_loss_sys (geoMatch.py:86-100,138-141)
+    ls = gin.sym_loss_inputs(M)
+    model.model_emb.sys_corr_idx = ls["sys_idx"]
+    model.model_emb.sys_idx = torch.from_numpy(ls["sys_idx"]).long()
+    rg = torch.from_numpy(ls["rgbd_f"]).requires_grad_(True)
+    mf = torch.from_numpy(ls["mesh_f"]).requires_grad_(True)
+    xs = dict(labels=torch.from_numpy(ls["labels"]), match_idx=torch.from_numpy(ls["match_idx"]),
+              visible_flag=torch.from_numpy(ls["vis"]), RT=torch.zeros(ls["labels"].shape[0], 3, 4))
+    mls = model.pointwise_feature_matching(rg, mf, xs)
+    mls.backward()
+    np.savez_compressed(os.path.join(HERE, "losses_sym.npz"), match_loss=mls.item(), rgbd_grad=rg.grad.numpy(),
+                        mesh_grad=mf.grad.numpy())
+    model.model_emb.sys_corr_idx = None
+
+    # ------------------------------------------------------------------ inference matching (evaluator.py:79-93, run from the mounted tree)
     env = dict(torch=torch, F=torch.nn.functional)
     env.update({k: torch.from_numpy(v) for k, v in gin.matching_inputs().items()})
-    exec("\n".join(stmts), env)
-    np.savez_compressed(os.path.join(HERE, "matching.npz"), statements=np.array(stmts),
+    exec("\n".join(evaluator_statements()), env)
+    np.savez_compressed(os.path.join(HERE, "matching.npz"),
                         cls_msk=env["cls_msk"].numpy(), max_th=env["max_th"].numpy(),
                         obj_pts_idx=env["obj_pts_idx"].numpy(), sim_corner=env["obj_pts_sim"][:64, :64].numpy())
 
@@ -285,11 +406,27 @@ def main():
     json.dump(dkeys, open(os.path.join(HERE, "dgcnn_state.json"), "w"), indent=0, sort_keys=True)
     dbatch = synthetic.make_batch(seed=8, batch=2, n_points=512)
     dx = torch.from_numpy(dbatch["cld_rgb_nrm"])
+    calls = []
+    real_knn = DG.knn
+
+    def recording_knn(x, k):
+        idx = real_knn(x, k)
+        calls.append(idx.numpy().astype(np.int32))
+        return idx
+    DG.knn = recording_knn                      # get_graph_feature looks `knn` up in the module globals
     with torch.no_grad():
-        dep = dmodel(dict(cld_rgb_nrm=dx))
+        dep = dmodel(dict(cld_rgb_nrm=dx))      # geoMatch_DGCNN.forward: cloud trunk (3 graphs) then mesh trunk (3 graphs)
+        n_fwd = len(calls)
         demb = dmodel.pcd_emb(dx)
+    DG.knn = real_knn
+    assert n_fwd == 6 and [c.shape for c in calls[:6]] == [(2, 512, 16)] * 3 + [(1, Md, 20)] * 3, [c.shape for c in calls]
+    with torch.no_grad():
         idx3 = DG.knn(dx[:, :3], 16)
+    assert np.array_equal(idx3.numpy(), calls[0])
     dg = dict(mesh_buffer=dmodel.model_emb.mesh.numpy(), knn_xyz=idx3.numpy().astype(np.int32))
+    for i in range(3):
+        dg["knn_cloud%d" % i] = calls[i].astype(np.int16)
+        dg["knn_mesh%d" % i] = calls[3 + i].astype(np.int16)
     for name, t in (("seg", dep["seg"]), ("rgbd", dep["rgbd"]), ("emb", demb), ("mesh", dep["mesh"])):
         pos, val = sample_entries(t, 4096, seed=len(name) + 40)
         dg[name + "_pos"], dg[name + "_val"] = pos, val

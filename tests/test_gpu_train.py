@@ -358,15 +358,26 @@ def test_training_step_through_fused_paths_equals_module_paths():
         l0, g0, s0 = run(())
         l1, g1, s1 = run(("USE_LOWRES_UPCONV_TRAIN", "USE_SPLIT_PSP_TRAIN"))
         l2, g2, s2 = run(tuple(n for _, n in flags))
+        # how ill-conditioned THIS step is: the module paths again on an image moved by one fp32 rounding (relative 2^-23 per
+        # pixel).  Which channels have a near-zero batch variance depends on the data, so the yardstick is measured, not assumed.
+        rgb0 = batch["rgb"].clone()
+        sign = torch.from_numpy(np.where(np.random.RandomState(3).rand(*rgb0.shape) < 0.5, -1.0, 1.0).astype(np.float32))
+        batch["rgb"] = rgb0 * (1.0 + sign * 2.0 ** -23)
+        ln, gn, _ = run(())
+        batch["rgb"] = rgb0
     finally:
         for mod, name in flags:
             setattr(mod, name, True)
     den = sum((v ** 2).sum().item() for v in g0.values()) ** 0.5
     dist = lambda g: sum(((g[k] - g0[k]) ** 2).sum().item() for k in g0) ** 0.5 / den
-    print("training A/B: loss %.6f / %.6f / %.6f, gradient distance exact paths %.3e, all paths %.3e" % (l0, l1, l2, dist(g1), dist(g2)))
+    noise = dist(gn)
+    print("training A/B: loss %.6f / %.6f / %.6f, gradient distance exact paths %.3e, all paths %.3e, one-rounding input noise %.3e"
+          % (l0, l1, l2, dist(g1), dist(g2), noise))
     assert np.isfinite(l0) and len(g0) > 300 and set(g0) == set(g1) == set(g2)
     assert abs(l1 - l0) < 1e-4 * abs(l0) and abs(l2 - l0) < 1e-3 * abs(l0), (l0, l1, l2)
     for k in s0:
         assert torch.allclose(s0[k], s1[k], rtol=5e-2, atol=1e-3) and torch.allclose(s0[k], s2[k], rtol=5e-2, atol=1e-3), k
-    assert dist(g1) < 3e-2, dist(g1)
+    # fp32 re-associations must stay within what ONE input rounding already does to this step (x10 for the number of re-associated
+    # sums), the split-bf16 / fp64-sum paths within a bound that only an O(1) error would break
+    assert dist(g1) < max(3e-2, 10.0 * noise), (dist(g1), noise)
     assert dist(g2) < 0.35, dist(g2)

@@ -129,3 +129,117 @@ def test_pose_solve_and_errors_match_reference_text():
         Rg, tg, pts = pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)
         assert pose_ref.add(T[:, :3], T[:, 3], Rg, tg, pts) == g["add"][b]
         assert abs(pose_ref.adi(T[:, :3], T[:, 3], Rg, tg, pts) - g["adi"][b]) < 1e-12
+
+
+# --------------------------------------------------------------------------------------------- round 2 fixtures
+def _c2_inputs():
+    B, N = 2, 2048
+    batch = synthetic.make_batch(seed=21, batch=B, n_points=N)
+    pyrs = [opyr.build_pyramid(batch["cld_rgb_nrm"][i, :3].T.copy(), batch["dpt_xyz"][i]) for i in range(B)]
+    inputs = {k: torch.from_numpy(batch[k]) for k in ("rgb", "cld_rgb_nrm", "choose", "labels")}
+    for key in pyrs[0]:
+        inputs[key] = torch.from_numpy(np.stack([p[key] for p in pyrs]))
+    return inputs
+
+
+def c2_mesh_features(M=8192):
+    """The fixed mesh descriptors the golden script's SplineCNN stand-in returned (same seeded stream)."""
+    return torch.from_numpy(np.random.RandomState(1234).randn(128, M).astype(np.float32))
+
+
+def test_headline_shape_forward_and_matching_match_reference_golden():
+    """N=2048 scene points x M=8192 model vertices (BASELINE configs[1] shape, batch 2): oracle pyramid == the loader's own
+    statements, oracle network == reference GeoMatch.forward, oracle matching == evaluator.py:79-93 on the same descriptors."""
+    g = np.load(os.path.join(G, "geomatch_eval_c2.npz"))
+    keys = json.load(open(os.path.join(G, "geomatch_state.json")))
+    sd = synthetic.synthetic_state_dict({k: torch.zeros(v) for k, v in keys.items()}, seed=0)
+    inputs = _c2_inputs()
+    for key in ("cld_nei_idx0", "r2p_ds_nei_idx0", "p2r_up_nei_idx2", "cld_interp_idx1"):
+        assert np.array_equal(inputs[key].numpy(), g["pyr_" + key]), key
+    mesh = c2_mesh_features()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = model_ref.geomatch_forward(sd, inputs, mesh)
+    for name in ("emb", "rgbd", "seg"):
+        t = out[name]
+        assert list(t.shape) == list(g[name + "_shape"])
+        got = t.reshape(-1)[torch.from_numpy(g[name + "_pos"])].numpy()
+        scale = max(1.0, float(np.abs(g[name + "_val"]).max()))
+        assert np.abs(got - g[name + "_val"]).max() < 2e-4 * scale, name
+        assert abs(t.double().norm().item() - float(g[name + "_norm"])) < 1e-4 * float(g[name + "_norm"])
+    for b in range(2):
+        msk = ops_ref.seg_mask(out["seg"][b])
+        gm = g["match_msk"][b]
+        assert (msk.numpy() != gm).mean() < 1e-3                      # seg logits differ by ~1e-4: a sign flip is a near-tie
+        both = torch.from_numpy(gm) & msk
+        val, idx, _ = ops_ref.match_argmax(out["rgbd"][b], mesh)
+        sel = both.numpy()
+        assert np.abs(val.numpy()[sel] - g["match_val"][b][sel]).max() < 1e-4
+        clear = sel & (g["match_gap"][b] > 2e-4)                       # arg-max is decided unless the runner-up is this close
+        assert np.array_equal(idx.numpy()[clear], g["match_idx"][b][clear])
+        assert clear.sum() > 0.9 * sel.sum()
+
+
+def test_training_matching_loss_matches_reference_golden():
+    """oracle/loss_ref (per-item loop, materialised mask) vs the imported reference: value and both gradients,
+    non-symmetric (geoMatch.py:55-83) and symmetric (geoMatch.py:86-100) objects."""
+    from oracle import loss_ref
+    g = np.load(os.path.join(G, "losses.npz"))
+    li = gin.loss_inputs()
+    rgbd = torch.from_numpy(li["rgbd_f"]).requires_grad_(True)
+    mesh = torch.from_numpy(li["mesh_f"]).requires_grad_(True)
+    ml = loss_ref.pointwise_feature_matching(rgbd, mesh, torch.from_numpy(li["labels"]), torch.from_numpy(li["match_idx"]),
+                                             torch.from_numpy(li["vis"]), torch.from_numpy(g["mesh_xyz"]), float(g["positive_r"]))
+    ml.backward()
+    assert abs(ml.item() - float(g["match_loss"])) < 1e-6 * max(1.0, abs(float(g["match_loss"])))
+    assert np.allclose(rgbd.grad.numpy(), g["rgbd_grad"], rtol=1e-4, atol=1e-8)
+    assert np.allclose(mesh.grad.numpy(), g["mesh_grad"], rtol=1e-4, atol=1e-8)
+    sim = torch.from_numpy(li["sim"]).requires_grad_(True)
+    cl = loss_ref.circle_loss(sim, torch.from_numpy(li["mask"]))
+    cl.backward()
+    assert abs(cl.item() - float(g["circle_loss"])) < 1e-6 and np.allclose(sim.grad.numpy(), g["circle_grad"], rtol=1e-4, atol=1e-9)
+
+    gs = np.load(os.path.join(G, "losses_sym.npz"))
+    ls = gin.sym_loss_inputs()
+    rgbd = torch.from_numpy(ls["rgbd_f"]).requires_grad_(True)
+    mesh = torch.from_numpy(ls["mesh_f"]).requires_grad_(True)
+    ml = loss_ref.pointwise_feature_matching(rgbd, mesh, torch.from_numpy(ls["labels"]), torch.from_numpy(ls["match_idx"]),
+                                             torch.from_numpy(ls["vis"]), None, 0.0, sys_idx=torch.from_numpy(ls["sys_idx"]))
+    ml.backward()
+    assert abs(ml.item() - float(gs["match_loss"])) < 1e-6 * max(1.0, abs(float(gs["match_loss"])))
+    assert np.allclose(rgbd.grad.numpy(), gs["rgbd_grad"], rtol=1e-4, atol=1e-8)
+    assert np.allclose(mesh.grad.numpy(), gs["mesh_grad"], rtol=1e-4, atol=1e-8)
+
+
+def test_front_end_arithmetic_matches_reference_dpt_2_pcld():
+    """synthetic.depth_to_xyz (the host generator every test input comes from) == the reference's dpt_2_pcld + float32 cast,
+    and the oracle's strided grids == the loader's sr2dptxyz, by SHA-256 of the float32 bytes (tests/golden/frontend.npz)."""
+    import hashlib
+    g = np.load(os.path.join(G, "frontend.npz"))
+    depth, _, _ = synthetic.make_frame(np.random.RandomState(77))
+    xyz = synthetic.depth_to_xyz(depth)
+    for tag in ("a", "b"):
+        x0, y0 = g["origin_" + tag]
+        clip = np.ascontiguousarray(xyz[y0:y0 + 256, x0:x0 + 256])
+        assert np.array_equal(clip.reshape(-1)[g["xyz_pos_" + tag]], g["xyz_val_" + tag])
+        assert hashlib.sha256(clip.tobytes()).hexdigest() == str(g["xyz_sha_" + tag])
+        for sc, grid in opyr.strided_xyz_grids(clip, 256).items():
+            assert hashlib.sha256(np.ascontiguousarray(grid).tobytes()).hexdigest() == str(g["grid%d_sha_%s" % (sc, tag)]), sc
+
+
+def test_dgcnn_dynamic_graphs_match_reference_golden():
+    """All six dynamic kNN graphs of the reference's DGCNN forward (3 cloud, 3 mesh) vs the oracle's: identical except where the
+    k-th and (k+1)-th candidates are a near-tie in fp32 (different GEMM summation order)."""
+    from oracle import dgcnn_ref
+    g = np.load(os.path.join(G, "dgcnn_eval.npz"))
+    keys = json.load(open(os.path.join(G, "dgcnn_state.json")))
+    sd = synthetic.synthetic_state_dict({k: torch.zeros(v) for k, v in keys.items() if k != "model_emb.mesh"}, seed=9)
+    sd["model_emb.mesh"] = torch.from_numpy(g["mesh_buffer"])
+    x = torch.from_numpy(synthetic.make_batch(seed=8, batch=2, n_points=512)["cld_rgb_nrm"])
+    with torch.no_grad():
+        graphs = dgcnn_ref.trunk_graphs(x, model_ref.SD(sd, "pcd_emb."), 16) + dgcnn_ref.trunk_graphs(sd["model_emb.mesh"], model_ref.SD(sd, "model_emb."), 20)
+    names = ["knn_cloud%d" % i for i in range(3)] + ["knn_mesh%d" % i for i in range(3)]
+    for name, (idx, dist) in zip(names, graphs):
+        want = torch.from_numpy(g[name].astype(np.int64))
+        bad = dgcnn_ref.graph_mismatch_not_near_tie(idx, want, dist, tol=1e-4)
+        assert bad == 0, (name, bad)
