@@ -8,6 +8,13 @@ Workload at N GPUs: BASELINE.json configs[1] per GPU (LineMOD obj_01, batch 16, 
 M=8192 model vertices, crop 256x256), one process per GPU, crops sharded across ranks with no
 data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
 
+The step is captured once in a hipGraph (after eager warm-up steps) and every timed step is one replay of it on the
+resident inputs: the same ~240 kernels, nothing cached or skipped, but one host call per step instead of ~240 (the
+eager loop needs ~5 ms of host time per step and one host core per rank).  `--eager` times the eager loop instead; the
+eager figure is also reported as an extra.  Further extras on a 1-GPU run (same JSON line): batch 32, strict-fp32
+arithmetic, the geoMatch_DGCNN variant, one training step at the reference's default training shape, and a roofline
+entry for each of the kernels that dominate the step.
+
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
@@ -44,6 +51,8 @@ def parse():
                     help="strict fp32 products everywhere: f32-MFMA matching, trunk convolutions / GEMMs on MIOpen / hipBLASLt "
                          "(default: split-bf16 MFMA, hi*hi+hi*lo+lo*hi with fp32 accumulation, |err| <= 3*2^-18 per product)")
     ap.add_argument("--cpu-crops", type=int, default=96, help="crops in the bounded CPU sample (~10-20 s of host work)")
+    ap.add_argument("--eager", action="store_true", help="time the eager step loop instead of hipGraph replays")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-32 / exact-f32 / DGCNN / training / per-kernel roofline legs")
     return ap.parse_args()
 
 
@@ -67,9 +76,10 @@ def usable_cores():
     return min(n, int(os.environ.get("GDM_CPU_CORES", "16")))
 
 
-def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
+def cpu_baseline(batch, sd_cpu, n_crops, B):
     """Reference CPU path as the oracle restates it (kNN leg through the compiled reference nanoflann when
-    oracle/_ref travelled with the snapshot): pyramid + FFB6DEmb + heads + matching, all host cores."""
+    oracle/_ref travelled with the snapshot): pyramid + FFB6DEmb + heads + matching per crop, and the SplineCNN mesh
+    branch once per batch of B crops (the reference's forward recomputes it per call, geoMatch.py:179), all host cores."""
     import numpy as np
     import torch
     from oracle import knn as oknn, model_ref, ops_ref, pyramid as opyr
@@ -79,8 +89,12 @@ def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
     search = opyr.ref_knn_search if use_ref else None
     t0 = time.perf_counter()
     nb = batch["rgb"].shape[0]
+    mesh_cpu = None
     for j in range(n_crops):
         i = j % nb
+        if j % B == 0:
+            with torch.no_grad():
+                mesh_cpu = model_ref.spline_mesh_forward(sd_cpu)
         pyr = opyr.build_pyramid(batch["cld_rgb_nrm"][i, :3].T.copy(), batch["dpt_xyz"][i], knn_search=search)
         inp = {k: torch.from_numpy(batch[k][i:i + 1]) for k in ("rgb", "cld_rgb_nrm", "choose")}
         inp.update({k: torch.from_numpy(v[None]) for k, v in pyr.items()})
@@ -91,9 +105,182 @@ def cpu_baseline(batch, sd_cpu, mesh_cpu, n_crops):
     dt = time.perf_counter() - t0
     return {"value": round(n_crops / dt, 4), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": "%d crops of the same workload (N=%d x M=%d): %s kNN pyramid (1 thread/call as shipped) + oracle torch-CPU "
-                      "FFB6DEmb+heads + matching on %d threads; mesh branch excluded (third-party op)" %
+                      "FFB6DEmb+heads + matching on %d threads + the mesh branch (oracle restatement of SplineConv, parity unpinned) "
+                      "once per %d crops" %
                       (n_crops, batch["cld_rgb_nrm"].shape[2], mesh_cpu.shape[1],
-                       "compiled reference nanoflann" if use_ref else "oracle brute-force", cores)}
+                       "compiled reference nanoflann" if use_ref else "oracle brute-force", cores, B)}
+
+
+def timed(fn, n, torch):
+    """Average ms of n back-to-back calls of fn on the current stream (one HIP event pair around all of them)."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def kernel_rooflines(torch, dev, B, N):
+    """Live HIP-event timings of the kernels that dominate the step besides the matching kernel, at the shapes the step
+    launches them with; each entry states its algorithmic work and the peak it is priced against."""
+    from geometric_aware_dense_matching_amd import _lib, ops, pyramid, synthetic
+    L = _lib.lib()
+    out = []
+    n = 20
+    # (1) trunk 3x3 convolution 512 -> 512 at 32 x 32 (ResNet-18 layer4, extractors.py:36-58), kernel alone on packed operands
+    Cin = Cout = 512
+    H = W = 32
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02
+    wpk = ops.conv3x3_pack_weight(w)
+    xpk = torch.zeros(L.gdm_conv3x3_act_bytes(B, Cin, H, W), dtype=torch.uint8, device=dev)
+    _lib.check(L.gdm_conv3x3_pack_act_hip(x.data_ptr(), B, Cin, H, W, xpk.data_ptr(), ops._stream()), "pack")
+    o = torch.empty(B, Cout, H, W, device=dev)
+    conv = lambda: _lib.check(L.gdm_conv3x3_packed_hip(xpk.data_ptr(), wpk.data_ptr(), None, None, None, B, Cin, Cout, H, W, 1,
+                                                       o.data_ptr(), ops._stream()), "conv")
+    for _ in range(3):
+        conv()
+    ms = timed(conv, n, torch)
+    fl = 2.0 * 9 * Cin * Cout * B * H * W
+    out.append({"kernel": "conv3x3_bf16x3_kernel 512->512 @32x32 (trunk layer4)", "bound": "mfma", "unit": "TFLOP/s",
+                "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4), "traffic": None,
+                "work": "2*9*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * H * W)})
+    # (2) neighbour pyramid, K = 16 searches (knn_wave_kernel): pair evaluations per second against the vector-ALU bound
+    batch = synthetic.make_batch(seed=100, batch=B, n_points=N)
+    cld = pyramid.cloud_from_inputs(torch.from_numpy(batch["cld_rgb_nrm"]).to(dev))
+    xyz = torch.from_numpy(batch["dpt_xyz"]).to(dev)
+    for _ in range(3):
+        pyramid.build_pyramid(cld, xyz)
+    ms = timed(lambda: pyramid.build_pyramid(cld, xyz), n, torch)
+    S2 = 256 * 256
+    lv = [N, N // 4, N // 16, N // 64, N // 256]
+    pairs = 0
+    for i, hw in enumerate((S2 // 16, S2 // 64, S2 // 64, S2 // 64)):
+        pairs += lv[i] * lv[i] + lv[i + 1] * lv[i] + 2 * hw * lv[i + 1]
+    for i, hw in enumerate((S2 // 16, S2 // 4, S2 // 4)):
+        pairs += 2 * hw * lv[3 - i]
+    pairs *= B
+    valu_peak = 256 * 4 * 32 * 2.4e9 / 9.0 / 1e12        # 9 vector ops per pair (3 sub, 3 mul, 2 add, 1 compare)
+    out.append({"kernel": "knn_wave_kernel + knn_kernel<1> + knn_pack_kernel (whole neighbour pyramid, 22 searches per crop)", "bound": "valu",
+                "unit": "Tpair/s", "achieved": round(pairs / ms / 1e9, 3), "peak": round(valu_peak, 2),
+                "frac": round(pairs / ms / 1e9 / valu_peak, 4), "avg_ms": round(ms, 4), "traffic": None,
+                "work": "%d brute-force pair distances per batch of %d crops; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 9 vector ops per pair" % (pairs, B)})
+    # (3) gather + max over K (random_sample, ffb6d.py:128-146): the largest call of the step, pixel -> point at 128 x 128
+    C, n_src, m, K = 64, 128 * 128, N // 4, 16
+    feat = torch.randn(B, C, n_src, device=dev)
+    idx = torch.randint(0, n_src, (B, m, K), device=dev, dtype=torch.int32)
+    for _ in range(3):
+        ops.gather_max(feat, idx)
+    ms = timed(lambda: ops.gather_max(feat, idx), n, torch)
+    by = 4.0 * B * (C * n_src + K * m + C * m)
+    out.append({"kernel": "gather_max_kernel<16> C=64, 16384 px -> %d points" % m, "bound": "hbm", "unit": "GB/s",
+                "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "avg_ms": round(ms, 4), "traffic": None, "work": "4*C*n_src + 4*K*n' + 4*C*n' bytes per crop (SURVEY.md 8d)"})
+    # (4) last up stage: PSPUpsample(64, 64) 128^2 -> 256^2 in one kernel
+    xs = torch.randn(B, 64, 128, 128, device=dev)
+    wk = ops.upconv_fused64_pack_weight(torch.randn(64, 64, 3, 3, device=dev) * 0.05)
+    sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    for _ in range(3):
+        ops.upconv_fused64(xs, wk, sc, sh, (256, 256), 2, 0.25)
+    ms = timed(lambda: ops.upconv_fused64(xs, wk, sc, sh, (256, 256), 2, 0.25), n, torch)
+    by = 4.0 * B * 64 * (128 * 128 + 256 * 256)
+    out.append({"kernel": "upconv_fused64_kernel 64->64, 128^2 -> 256^2", "bound": "hbm", "unit": "GB/s",
+                "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "avg_ms": round(ms, 4), "traffic": None, "work": "reads 64 ch at 128^2 once, writes 64 ch at 256^2 once"})
+    return out
+
+
+def extra_legs(torch, dev, args, model, N, M):
+    """Driver-visible figures beyond the headline (1-GPU runs only): batch 32 (north_star quotes its end-to-end target there),
+    strict-fp32 arithmetic, the geoMatch_DGCNN variant (BASELINE config 4) and one training step (config 3's per-GPU work)."""
+    import numpy as np
+    from geometric_aware_dense_matching_amd import infer, matching, ops, pyramid, settings, synthetic, train_lm
+    from geometric_aware_dense_matching_amd.config import make_model_cfg
+    from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+    out = {}
+    prec = "bf16x3" if args.precision == "bf16x3" else "f32"
+
+    def dev_batch(seed, B):
+        b = synthetic.make_batch(seed=seed, batch=B, n_points=N)
+        return {k: torch.from_numpy(b[k]).to(dev) for k in ("rgb", "cld_rgb_nrm", "choose", "dpt_xyz")}
+
+    # ---- batch 32, hipGraph replay (pyramid + forward + matching)
+    gp = infer.GraphedPipeline(model, dev_batch(300, 32), precision=prec, with_pose=False)
+    ms = timed(gp.graph.replay, 10, torch)
+    out["b32"] = {"crops_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "hipGraph replay"}
+    del gp
+
+    # ---- strict fp32: f32-MFMA matching, trunk convolutions / GEMMs back on MIOpen / hipBLASLt (no split-bf16 anywhere), eager
+    if not args.exact_f32:
+        saved = (settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM)
+        settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM = False, False
+        try:
+            d = dev_batch(301, args.batch)
+
+            def f32_step():
+                x = dict(d)
+                x.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(x["cld_rgb_nrm"]), x["dpt_xyz"]))
+                return matching.match_frames(model(x), precision="f32")
+            with torch.no_grad():
+                for _ in range(3):
+                    f32_step()
+                torch.cuda.synchronize()
+                ms = timed(f32_step, 5, torch)
+            out["exact_f32"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager",
+                                "batch": args.batch}
+        finally:
+            settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM = saved
+
+    # ---- geoMatch_DGCNN variant: eval forward + matching at the same shape
+    from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
+    dg = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=M), 1,
+                       model_points=synthetic.make_model_points(1, M)).to(dev).eval()
+    d = dev_batch(302, args.batch)
+
+    def dg_step():
+        return matching.match_frames(dg(d), precision=prec)
+    with torch.no_grad():
+        for _ in range(3):
+            dg_step()
+        torch.cuda.synchronize()
+        ms = timed(dg_step, 5, torch)
+    out["dgcnn"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager", "batch": args.batch,
+                    "config": "geoMatch_DGCNN (k=16 cloud, k=20 mesh), N=%d x M=%d, fwd + matching" % (N, M)}
+    del dg
+
+    # ---- one training step (fwd + fused matching loss + bwd + Adam) at the reference's default training shape
+    Bt, Nt, Mt = 24, 4096, 4096                                   # config/lmo_cfg.py:95-98,119
+    find = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False                        # MIOpen default algorithms: find mode over ~100 backward shapes takes minutes
+    try:
+        tm = GeoMatch(make_model_cfg(n_mesh_node=Mt, num_points=Nt), 1, model_points=synthetic.make_model_points(1, Mt)).to(dev).train()
+        opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
+        ds = train_lm.SyntheticCrops(Bt, Nt, Mt, seed=0)
+        cu = train_lm.to_device(torch.utils.data.default_collate([ds[i] for i in range(Bt)]), dev)
+
+        def train_step():
+            o, _ = train_lm.model_fn_dec(tm, cu, dev)
+            o["loss"].backward()
+            opt.step()
+            opt.zero_grad()
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out["train"] = {"train_ms_per_step": round(ms, 2), "crops_per_s": round(Bt / ms * 1e3, 1), "batch": Bt, "n_points": Nt, "n_model": Mt,
+                        "what": "fwd + losses + bwd + Adam on one GPU (per-GPU work of config 3 without the RCCL all-reduce)"}
+        del tm, opt
+    finally:
+        torch.backends.cudnn.benchmark = find
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -172,16 +359,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    graph = None
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
         sync_all()
+        if not args.eager:
+            # one capture of the whole step on the resident inputs (after the eager warm-up above: MIOpen has picked its kernels,
+            # the per-module caches are filled); every timed step below is one replay = the same kernels, one host call
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = step()
+            graph.replay()
+            sync_all()
+            ref = step()
+            sync_all()
+            assert torch.equal(graph_out[0], ref[0]) and torch.equal(graph_out[1], ref[1]), "graph replay != eager step"
+        run_step = graph.replay if graph is not None else step
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step()
+            run_step()
         sync_all()
         dt = time.perf_counter() - t0
-        # stage breakdown from a few more, instrumented, steps OUTSIDE the timed region: five event records per step cost
+        # the other launch form, for the record (rank 0 extras): eager loop when the headline is the graph, and vice versa
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        dt_eager = time.perf_counter() - t1
+        # stage breakdown from a few more, instrumented, eager steps OUTSIDE the timed region: five event records per step cost
         # ~1 % of the step (marker packets drain the queue between kernels)
         for _ in range(min(args.steps, 5)):
             step(record=True)
@@ -259,23 +465,31 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cpu = cpu_baseline(batch, sd_cpu, ep["mesh"][0].detach().cpu(), args.cpu_crops)
+        cpu = cpu_baseline(batch, sd_cpu, args.cpu_crops, B)
+
+    extras, rooflines = None, None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "eager_crops_per_s": round(B * args.steps / dt_eager, 1)}
+        extras.update(extra_legs(torch, dev, args, model, N, M))
+        rooflines = [dict(roofline, name="match materialised"), dict(roofline_fused, name="match fused")] + kernel_rooflines(torch, dev, B, N)
 
     if rank == 0:
+        arith = "exact f32" if args.exact_f32 else ("split-bf16 MFMA x3 (fp32 accumulate) for matching, 32x32-res 3x3 convs and large "
+                                                    "1x1 mixes; f32 elsewhere")
         line = {
             "metric": "rgbd_crops_per_sec_geomatch_fwd", "value": round(value, 2), "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.exact_f32 else "bf16x3/f32acc", "data": "synthetic",
             "config": {"workload": "LineMOD obj_01 batch=%d/GPU, N=%d scene pts x M=%d model kps, crop 256x256, geoMatch "
                                    "(CNN+RandLA+SplineCNN) fwd-only + kNN pyramid + matching" % (B, N, M),
                        "batch_per_gpu": B, "global_batch": B * world, "n_points": N, "n_model": M,
-                       "match_precision": args.precision,
-                       "product_arithmetic": "exact f32" if args.exact_f32 else "split-bf16 MFMA x3 (fp32 accumulate) for matching, 32x32-res "
-                                             "3x3 convs and large 1x1 mixes; f32 elsewhere",
+                       "match_precision": args.precision, "product_arithmetic": arith,
+                       "launch": "eager (one host call per kernel)" if args.eager else "hipGraph replay of the whole step (one host call per step)",
                        "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
             "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
                          "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
-            "roofline": roofline, "roofline_fused": roofline_fused, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_fused": roofline_fused, "rooflines": rooflines, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:

@@ -21,22 +21,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
-from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval
+from . import ops, settings
+from .layers import act_code, cached_gemm_weight, folded_bn, fused_eval
 
 
-# the low-resolution form of conv3x3(upsample(x)) needs a 9*Cout-channel intermediate: it pays when Cin is large
-UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
-# GDM_MFMA_CONV=0 keeps every trunk convolution on MIOpen (A/B switch)
-USE_MFMA_CONV = os.environ.get("GDM_MFMA_CONV", "1") != "0"
-# GDM_MFMA_CONV_TRAIN=0 keeps the training forward / input-gradient of those convolutions on MIOpen (A/B switch)
-USE_MFMA_CONV_TRAIN = os.environ.get("GDM_MFMA_CONV_TRAIN", "1") != "0"
-# GDM_FUSED_UPCONV=0 keeps the 64 -> 64 up stage on the two-kernel form (low-resolution GEMM + gather) (A/B switch)
-USE_FUSED_UPCONV = os.environ.get("GDM_FUSED_UPCONV", "1") != "0"
-# GDM_LOWRES_UPCONV_TRAIN=0 keeps PSPUpsample's training path on upsample + MIOpen convolution (A/B switch)
-USE_LOWRES_UPCONV_TRAIN = os.environ.get("GDM_LOWRES_UPCONV_TRAIN", "1") != "0"
-# GDM_SPLIT_PSP_TRAIN=0 keeps PSPModule's training path on upsampled priors + concat + the 5F-channel bottleneck convolution (A/B switch)
-USE_SPLIT_PSP_TRAIN = os.environ.get("GDM_SPLIT_PSP_TRAIN", "1") != "0"
 
 
 def bn_act(bn, x, relu=None):
@@ -75,12 +63,12 @@ class BasicBlock(nn.Module):
     def _train_conv(conv, x):
         """Training: forward and input gradient of the 32x32-resolution 3x3 convolutions on the split-bf16 MFMA kernel (MIOpen's fp32
         Winograd runs them 3x slower); the weight gradient stays with MIOpen."""
-        if USE_MFMA_CONV_TRAIN and conv.bias is None and ops.conv3x3_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation):
+        if settings.USE_MFMA_CONV_TRAIN and conv.bias is None and ops.conv3x3_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation):
             return ops.conv3x3_train(x, conv.weight)
         return conv(x)
 
     def _mfma_ok(self, x):
-        return (USE_MFMA_CONV and ops.conv3x3_supported(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation)
+        return (settings.USE_MFMA_CONV and ops.conv3x3_supported(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation)
                 and ops.conv3x3_supported(x, self.conv2.weight, self.conv2.stride, self.conv2.padding, self.conv2.dilation)
                 and self.conv2.weight.shape[1] == self.conv1.weight.shape[0])
 
@@ -180,7 +168,7 @@ class PSPModule(nn.Module):
             # no full-resolution priors
             ms, wf = self._split_weights()
             B, Cin = feats.shape[0], feats.shape[1]
-            if USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
+            if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
                 wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
                 g = ops.gemm_bf16x3(feats.reshape(B, Cin, h * w), wpk, co).view(B, -1, h, w)
             else:
@@ -194,7 +182,7 @@ class PSPModule(nn.Module):
                 ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
             return ops.psp_combine(g, ys, self.bottleneck.bias)
         sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
-        if (USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
+        if (settings.USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
                 and (h * w) % 4 == 0 and feats.shape[0] * self.bottleneck.out_channels <= 65535 and h <= 64 and w <= 64):
             # training: the same algebra as the eval path, under autograd.  W cat(up(V_k pool_k f)..., f) = W_f f + sum_k up((W_k V_k) pool_k f):
             # the big GEMM has K = F instead of 5F in forward, dgrad and wgrad, the four full-resolution priors and their concat are
@@ -241,11 +229,11 @@ class PSPUpsample(nn.Module):
         if fused_eval(x, self):
             code = act_code(self.conv[3])
             conv = self.conv[1]
-            if code is not None and x.shape[0] * conv.out_channels <= 65535 and conv.in_channels >= UPCONV_MIN_CIN:
+            if code is not None and x.shape[0] * conv.out_channels <= 65535 and conv.in_channels >= settings.UPCONV_MIN_CIN:
                 # conv3x3(up(x)) = 9-tap bilinear gather of a LOW-resolution 1x1 convolution (4x fewer FLOPs, no
                 # 2x-resolution intermediate), BN (with the conv bias) + PReLU folded into the gather's epilogue
                 Bx, Cin, Hx, Wx = x.shape
-                if USE_FUSED_UPCONV and Cin == 64 and conv.out_channels == 64 and Hx >= 2 and Wx >= 2 and Bx <= 65535:
+                if settings.USE_FUSED_UPCONV and Cin == 64 and conv.out_channels == 64 and Hx >= 2 and Wx >= 2 and Bx <= 65535:
                     # 64 -> 64 (last up stage): channel mix on the matrix cores into LDS + gather in ONE kernel, no 9*64-channel tensor
                     w = conv.weight
                     key = (w._version, w.data_ptr())
@@ -255,7 +243,7 @@ class PSPUpsample(nn.Module):
                         self.__dict__["_gdm_fused64"] = cache
                     scale, shift = folded_bn(self.conv[2], conv.bias)
                     return ops.upconv_fused64(x, cache[1], scale, shift, (Hx * 2, Wx * 2), code[0], code[1])
-                if USE_MFMA_GEMM and ops.gemm_supported(Cin, 9 * conv.out_channels, Hx * Wx):
+                if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, 9 * conv.out_channels, Hx * Wx):
                     wpk, c9 = cached_gemm_weight(self, "tap", self._tap_major_weight, (conv.weight,))
                     z = ops.gemm_bf16x3(x.reshape(Bx, Cin, Hx * Wx), wpk, c9).view(Bx, -1, Hx, Wx)      # split-bf16 MFMA
                 else:
@@ -265,7 +253,7 @@ class PSPUpsample(nn.Module):
         act = self.conv[3]
         if x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and x.dtype == torch.float32:
             conv = self.conv[1]
-            if USE_LOWRES_UPCONV_TRAIN and ops.upconv_train_supported(x.shape[0], conv.out_channels) and conv.in_channels >= UPCONV_MIN_CIN:
+            if settings.USE_LOWRES_UPCONV_TRAIN and ops.upconv_train_supported(x.shape[0], conv.out_channels) and conv.in_channels >= settings.UPCONV_MIN_CIN:
                 # training too: the 3x3 convolution on the upsampled map as a low-resolution GEMM (autograd) + the differentiable
                 # 9-tap gather: 4x fewer FLOPs forward and backward, no 2x-resolution input, MIOpen's fp32 wrw / bwd-data not needed
                 Bx, Cin, Hx, Wx = x.shape

@@ -12,9 +12,9 @@ Neighbour indices are consumed as int32 (int64 accepted and narrowed).
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, settings
 from .cnn import PSPNet, bn_act
-from .layers import USE_MFMA_GEMM, act_code, cached_gemm_weight, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
+from .layers import act_code, cached_gemm_weight, folded_bn, fused_eval, pt_conv2d, rl_conv1d, rl_conv2d
 from .randla import DilatedResBlock
 
 
@@ -135,7 +135,7 @@ class FFB6DEmb(nn.Module):
                     y = ops.conv1x1_gather_add_act(rgb_emb0.reshape(bs, c, hr * wr), self._fuse_weight_t(fuse_layer, wa), t,
                                                    idx.reshape(bs, -1), scale, shift, code[0], code[1])
                     return y.view(bs, -1, hr, wr)
-                if USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
+                if settings.USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
                     wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
                     x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA
                 else:

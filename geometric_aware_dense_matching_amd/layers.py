@@ -50,7 +50,6 @@ def cached_gemm_weight(owner, tag, weight2d, deps):
     return cache[1], cache[2]
 
 
-USE_MFMA_GEMM = __import__("os").environ.get("GDM_MFMA_GEMM", "1") != "0"
 
 
 def act_code(act):

@@ -18,7 +18,7 @@ Operator <-> reference map (file:line under /root/reference):
 """
 import torch
 
-from . import _lib
+from . import _lib, settings
 from ._lib import KnnJob, check
 
 MATCH_BF16X3 = 0
@@ -451,9 +451,6 @@ class _BatchNormAct(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
-USE_FUSED_BN_TRAIN = __import__("os").environ.get("GDM_FUSED_BN_TRAIN", "1") != "0"
-# GDM_FUSED_SYNCBN=0 keeps nn.SyncBatchNorm modules on torch's implementation (A/B switch)
-USE_FUSED_SYNCBN = __import__("os").environ.get("GDM_FUSED_SYNCBN", "1") != "0"
 
 
 def _sync_group(bn):
@@ -468,9 +465,9 @@ def _sync_group(bn):
 def bn_train_supported(x, bn):
     """Affine BatchNorm{1,2}d -- or SyncBatchNorm -- in training mode with torch-style running statistics, on a contiguous f32 GPU map
     whose inner size is a multiple of 4."""
-    if not (USE_FUSED_BN_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous()):
+    if not (settings.USE_FUSED_BN_TRAIN and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous()):
         return False
-    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d) and not (USE_FUSED_SYNCBN and type(bn) is torch.nn.SyncBatchNorm):
+    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d) and not (settings.USE_FUSED_SYNCBN and type(bn) is torch.nn.SyncBatchNorm):
         return False
     if not bn.affine or bn.momentum is None or not bn.track_running_stats:
         return False

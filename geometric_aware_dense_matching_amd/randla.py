@@ -16,11 +16,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, settings
 from .layers import folded_bn, fused_eval, rl_conv2d
 
-# GDM_FUSED_LFA=0 keeps the attentive-pooling stages on the separate gather / GEMM / pooling kernels (A/B switch)
-USE_FUSED_LFA = __import__("os").environ.get("GDM_FUSED_LFA", "1") != "0"
 
 
 class AttPooling(nn.Module):
@@ -67,7 +65,7 @@ class BuildingBlock(nn.Module):
 
     def _fusable(self, feature, neigh_idx):
         acts = (self.mlp1, self.mlp2, self.att_pooling_1.mlp, self.att_pooling_2.mlp)
-        return (USE_FUSED_LFA and fused_eval(feature, self) and ops.lfa_supported(2 * feature.shape[1], neigh_idx.shape[-1])
+        return (settings.USE_FUSED_LFA and fused_eval(feature, self) and ops.lfa_supported(2 * feature.shape[1], neigh_idx.shape[-1])
                 and all(isinstance(getattr(m, "activation", None), nn.LeakyReLU) and m.activation.negative_slope == 0.2
                         and m.conv.bias is None for m in acts))
 

@@ -1,0 +1,42 @@
+"""Runtime A/B switches of the package, in ONE place.  Every switch selects between a hand-written HIP path and the plain
+form it replaces (the form the parity tests tie it to); all default to the HIP path.  They are read at CALL time
+(`settings.USE_X`), so a test or a benchmark may flip one between two calls; the `GDM_*` environment variables only set
+the initial values.
+
+    switch                     env                        off =
+    USE_MFMA_CONV              GDM_MFMA_CONV              trunk 3x3 convolutions (eval) on MIOpen
+    USE_MFMA_CONV_TRAIN        GDM_MFMA_CONV_TRAIN        trunk 3x3 convolutions' training forward / dgrad on MIOpen
+    USE_MFMA_GEMM              GDM_MFMA_GEMM              large 1x1 mixes on hipBLASLt fp32
+    USE_FUSED_UPCONV           GDM_FUSED_UPCONV           PSPUpsample(64,64) as low-resolution GEMM + gather (two kernels)
+    USE_LOWRES_UPCONV_TRAIN    GDM_LOWRES_UPCONV_TRAIN    PSPUpsample training path = upsample + MIOpen convolution
+    USE_SPLIT_PSP_TRAIN        GDM_SPLIT_PSP_TRAIN        PSPModule training path = upsampled priors + concat + 5F bottleneck
+    USE_FUSED_LFA              GDM_FUSED_LFA              RandLA attentive pooling on the separate gather / GEMM / pooling kernels
+    USE_GROUPED_SPLINE         GDM_GROUPED_SPLINE         128-channel SplineConv layers on the dense [M, 125*out] GEMM
+    USE_FUSED_BN_TRAIN         GDM_FUSED_BN_TRAIN         training BatchNorm + activation on the torch modules
+    USE_FUSED_SYNCBN           GDM_FUSED_SYNCBN           nn.SyncBatchNorm on torch's implementation
+    USE_FUSED_MATCH_LOSS       GDM_FUSED_MATCH_LOSS       training similarity materialised by hipBLASLt, rows kernel for the circle loss
+    UPCONV_MIN_CIN             GDM_UPCONV_MIN_CIN         (int) smallest Cin for the low-resolution form of conv3x3(upsample(x))
+"""
+import os
+
+
+def _flag(name, default="1"):
+    return os.environ.get(name, default) != "0"
+
+
+USE_MFMA_CONV = _flag("GDM_MFMA_CONV")
+USE_MFMA_CONV_TRAIN = _flag("GDM_MFMA_CONV_TRAIN")
+USE_MFMA_GEMM = _flag("GDM_MFMA_GEMM")
+USE_FUSED_UPCONV = _flag("GDM_FUSED_UPCONV")
+USE_LOWRES_UPCONV_TRAIN = _flag("GDM_LOWRES_UPCONV_TRAIN")
+USE_SPLIT_PSP_TRAIN = _flag("GDM_SPLIT_PSP_TRAIN")
+USE_FUSED_LFA = _flag("GDM_FUSED_LFA")
+USE_GROUPED_SPLINE = _flag("GDM_GROUPED_SPLINE")
+USE_FUSED_BN_TRAIN = _flag("GDM_FUSED_BN_TRAIN")
+USE_FUSED_SYNCBN = _flag("GDM_FUSED_SYNCBN")
+USE_FUSED_MATCH_LOSS = _flag("GDM_FUSED_MATCH_LOSS")
+UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
+
+ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
+                "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
+                "USE_FUSED_MATCH_LOSS")

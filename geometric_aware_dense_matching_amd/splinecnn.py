@@ -23,14 +23,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, ops
+from . import _lib, ops, settings
 from ._lib import check
-from .layers import USE_MFMA_GEMM, cached_gemm_weight
+from .layers import cached_gemm_weight
 from .synthetic import COLOR_MEAN, COLOR_STD_MESH
 
 KERNEL_SIZE = 5
-# GDM_GROUPED_SPLINE=0 keeps the 128-channel SplineConv layers on the dense [M, 125*out] GEMM (A/B switch)
-USE_GROUPED_SPLINE = os.environ.get("GDM_GROUPED_SPLINE", "1") != "0"
 
 
 class _SplineAggregate(torch.autograd.Function):
@@ -97,7 +95,7 @@ class SplineConv(nn.Module):
                                                    cache[1].data_ptr(), self.bias.data_ptr(), M, self.cin, self.cout, KERNEL_SIZE, int(relu),
                                                    out.data_ptr(), ops._stream()), "gdm_spline_direct_hip")
             return out
-        if (USE_MFMA_GEMM and USE_GROUPED_SPLINE and pairs is not None and not torch.is_grad_enabled() and x.is_cuda
+        if (settings.USE_MFMA_GEMM and settings.USE_GROUPED_SPLINE and pairs is not None and not torch.is_grad_enabled() and x.is_cuda
                 and self.cin % 128 == 0 and self.cout == 128):
             # edge-grouped form: only the (source, kernel index) pairs some edge needs are multiplied (about a quarter of the dense
             # [M, 125*out] table, which is then never written), on the same split-bf16 MFMA kernel with gathered rows
@@ -110,7 +108,7 @@ class SplineConv(nn.Module):
                                                             root.data_ptr(), self.bias.data_ptr(), M, self.cout, int(relu), out.data_ptr(),
                                                             ops._stream()), "gdm_spline_pairs_aggregate_hip")
             return out
-        if (USE_MFMA_GEMM and not torch.is_grad_enabled() and x.is_cuda
+        if (settings.USE_MFMA_GEMM and not torch.is_grad_enabled() and x.is_cuda
                 and ops.gemm_supported(self.cin, nk * self.cout, M)):
             # dense part on the split-bf16 MFMA GEMM, written node-major ([M, 125*out]) as the aggregation kernel reads it
             wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin),

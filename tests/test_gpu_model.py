@@ -16,7 +16,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, G)
 import inputs as gin  # noqa: E402
 
-from geometric_aware_dense_matching_amd import synthetic  # noqa: E402
+from geometric_aware_dense_matching_amd import settings, synthetic  # noqa: E402
 from geometric_aware_dense_matching_amd.config import make_model_cfg  # noqa: E402
 
 
@@ -470,11 +470,11 @@ def test_fused_upconv64_equals_upsample_conv_bn_prelu(B, H, W):
     bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
     x = torch.randn(B, 64, H, W, device="cuda")
     with torch.no_grad():
-        cnn.USE_FUSED_UPCONV = True
+        settings.USE_FUSED_UPCONV = True
         got = mod(x)
-        cnn.USE_FUSED_UPCONV = False
+        settings.USE_FUSED_UPCONV = False
         two = mod(x)
-        cnn.USE_FUSED_UPCONV = True
+        settings.USE_FUSED_UPCONV = True
         conv, act = mod.conv[1], mod.conv[3]
         up = torch.nn.functional.interpolate(x.double(), size=(2 * H, 2 * W), mode="bilinear", align_corners=True)
         y = torch.nn.functional.conv2d(up, conv.weight.double(), conv.bias.double(), padding=1)
@@ -484,3 +484,31 @@ def test_fused_upconv64_equals_upsample_conv_bn_prelu(B, H, W):
     scale = max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() < 3e-5 * scale
     assert (got - two).abs().max().item() < 3e-5 * scale
+
+
+def test_every_runtime_switch_off_gives_the_same_eval_forward(golden_model):
+    """settings.py: each A/B switch selects between a HIP path and the plain form it replaces; flipping any ONE of them off (and
+    all of them off together) must reproduce the default eval forward (2e-4 x scale: split-bf16 products vs fp32 libraries)."""
+    from geometric_aware_dense_matching_amd import pyramid
+    model, _ = golden_model
+    batch = synthetic.make_batch(seed=41, batch=2, n_points=1024)
+    d = _dev_inputs(batch)
+    d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"]))
+
+    def run():
+        with torch.no_grad():
+            ep = model(dict(d))
+        return ep["rgbd"].clone(), ep["seg"].clone(), ep["mesh"].clone()
+    base = run()
+    saved = {n: getattr(settings, n) for n in settings.ALL_SWITCHES}
+    try:
+        for case in [(n,) for n in settings.ALL_SWITCHES] + [tuple(settings.ALL_SWITCHES)]:
+            for n in settings.ALL_SWITCHES:
+                setattr(settings, n, n not in case)
+            got = run()
+            for a, b, name in zip(got, base, ("rgbd", "seg", "mesh")):
+                scale = max(1.0, b.abs().max().item())
+                assert (a - b).abs().max().item() < 2e-4 * scale, (case, name)
+    finally:
+        for n, v in saved.items():
+            setattr(settings, n, v)

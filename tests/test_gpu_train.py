@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
-from geometric_aware_dense_matching_amd import synthetic  # noqa: E402
+from geometric_aware_dense_matching_amd import settings, synthetic  # noqa: E402
 from geometric_aware_dense_matching_amd.config import make_model_cfg  # noqa: E402
 
 
@@ -131,14 +131,14 @@ def test_pspupsample_lowres_training_path_matches_reference_path(B, Cin, Cout, H
     w = torch.randn(B, Cout, 2 * H, 2 * W, device="cuda")
     res = {}
     for flag in (False, True):
-        cnn.USE_LOWRES_UPCONV_TRAIN = flag
+        settings.USE_LOWRES_UPCONV_TRAIN = flag
         for p in mod.parameters():
             p.grad = None
         x.grad = None
         y = mod(x)
         (y * w).sum().backward()
         res[flag] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
-    cnn.USE_LOWRES_UPCONV_TRAIN = True
+    settings.USE_LOWRES_UPCONV_TRAIN = True
     for a, b in zip(res[False], res[True]):
         scale = max(1.0, a.abs().max().item())
         assert (a - b).abs().max().item() < 2e-4 * scale
@@ -186,14 +186,14 @@ def test_pspmodule_split_training_path_matches_reference_path(B, F, Cout, H, W):
     w = torch.randn(B, Cout, H, W, device="cuda")
     res = {}
     for flag in (False, True):
-        cnn.USE_SPLIT_PSP_TRAIN = flag
+        settings.USE_SPLIT_PSP_TRAIN = flag
         for p in mod.parameters():
             p.grad = None
         x.grad = None
         y = mod(x)
         (y * w).sum().backward()
         res[flag] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
-    cnn.USE_SPLIT_PSP_TRAIN = True
+    settings.USE_SPLIT_PSP_TRAIN = True
     for a, b in zip(res[False], res[True]):
         scale = max(1.0, a.abs().max().item())
         assert (a - b).abs().max().item() < 2e-4 * scale
@@ -340,7 +340,7 @@ def test_training_step_through_fused_paths_equals_module_paths():
     state = {k: v.clone() for k, v in model.state_dict().items()}
     ds = train_lm.SyntheticCrops(B, N, M, seed=5)
     batch = torch.utils.data.default_collate([ds[i] for i in range(B)])
-    flags = [(cnn, "USE_LOWRES_UPCONV_TRAIN"), (cnn, "USE_SPLIT_PSP_TRAIN"), (cnn, "USE_MFMA_CONV_TRAIN"), (ops, "USE_FUSED_BN_TRAIN")]
+    flags = [(settings, "USE_LOWRES_UPCONV_TRAIN"), (settings, "USE_SPLIT_PSP_TRAIN"), (settings, "USE_MFMA_CONV_TRAIN"), (settings, "USE_FUSED_BN_TRAIN")]
 
     def run(on):
         for mod, name in flags:

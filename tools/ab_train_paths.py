@@ -4,7 +4,7 @@ Development aid."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from geometric_aware_dense_matching_amd import cnn, ops, train_lm, synthetic
+from geometric_aware_dense_matching_amd import cnn, ops, train_lm, synthetic, settings
 from geometric_aware_dense_matching_amd.config import make_model_cfg
 from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
 
@@ -15,7 +15,7 @@ model = GeoMatch(make_model_cfg(n_mesh_node=M, num_points=N), 1, model_points=sy
 state = {k: v.clone() for k, v in model.state_dict().items()}
 ds = train_lm.SyntheticCrops(B, N, M, seed=5)
 batch = torch.utils.data.default_collate([ds[i] for i in range(B)])
-flags = [(cnn, "USE_LOWRES_UPCONV_TRAIN"), (cnn, "USE_SPLIT_PSP_TRAIN"), (cnn, "USE_MFMA_CONV_TRAIN"), (ops, "USE_FUSED_BN_TRAIN")]
+flags = [(settings, "USE_LOWRES_UPCONV_TRAIN"), (settings, "USE_SPLIT_PSP_TRAIN"), (settings, "USE_MFMA_CONV_TRAIN"), (settings, "USE_FUSED_BN_TRAIN")]
 
 
 def run(on):

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from geometric_aware_dense_matching_amd import cnn
+from geometric_aware_dense_matching_amd import cnn, settings
 def tm(f, n=20):
     for _ in range(3): f()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -14,6 +14,6 @@ mod = cnn.PSPUpsample(64, 64).cuda().eval()
 for B, H in ((16, 128), (16, 64), (1, 128)):
     x = torch.randn(B, 64, H, H, device="cuda")
     with torch.no_grad():
-        cnn.USE_FUSED_UPCONV = False; t0 = tm(lambda: mod(x))
-        cnn.USE_FUSED_UPCONV = True; t1 = tm(lambda: mod(x))
+        settings.USE_FUSED_UPCONV = False; t0 = tm(lambda: mod(x))
+        settings.USE_FUSED_UPCONV = True; t1 = tm(lambda: mod(x))
     print("B=%2d %3d->%3d: two kernels %7.1f us   fused %7.1f us" % (B, H, 2 * H, t0, t1))

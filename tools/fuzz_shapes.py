@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from geometric_aware_dense_matching_amd import ops, randla
+from geometric_aware_dense_matching_amd import ops, randla, settings
 rs = np.random.RandomState(0)
 bad = 0
 def chk(name, ok, info):
@@ -51,8 +51,8 @@ for it in range(16):
     xyz = torch.randn(B, n, 3, device="cuda"); feat = torch.randn(B, d_out // 2, n, 1, device="cuda")
     idx = torch.randint(0, n, (B, n, 16), device="cuda", dtype=torch.int32)
     with torch.no_grad():
-        randla.USE_FUSED_LFA = False; ref = blk(xyz, feat, idx)
-        randla.USE_FUSED_LFA = True; got = blk(xyz, feat, idx)
+        settings.USE_FUSED_LFA = False; ref = blk(xyz, feat, idx)
+        settings.USE_FUSED_LFA = True; got = blk(xyz, feat, idx)
     chk("lfa", (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (d_out, n, B))
 torch.cuda.synchronize()
 print("fuzz done, mismatches:", bad)
