@@ -13,6 +13,8 @@ from .loss import AutomaticWeightedLoss, CircleLoss, FocalLoss
 
 
 class GeoMatch(nn.Module):
+    needs_pyramid = False            # dynamic graphs are built inside the trunks; no neighbour pyramid in the inputs
+
     def __init__(self, cfg, cls_id, model_points=None):
         super().__init__()
         self.awl = AutomaticWeightedLoss(2)

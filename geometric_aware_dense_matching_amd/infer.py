@@ -23,9 +23,9 @@ def run_multi_object(model_dict, inputs, cls_ids, with_pose=True, precision="bf1
             sel = [i for i, c in enumerate(cls) if c == cid]
             idx = torch.tensor(sel, device=inputs["cld_rgb_nrm"].device)
             sub = {k: v.index_select(0, idx) for k, v in inputs.items() if torch.is_tensor(v) and v.shape[:1] == (bs,)}
-            if "cld_nei_idx0" not in sub:
-                sub.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(sub["cld_rgb_nrm"]), sub["dpt_xyz"]))
             model = model_dict[cid]
+            if getattr(model, "needs_pyramid", True) and "cld_nei_idx0" not in sub:
+                sub.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(sub["cld_rgb_nrm"]), sub["dpt_xyz"]))
             ep = model(sub)
             res = matching.match_frames(ep, precision=precision)
             part = dict(seg=ep["seg"], rgbd=ep["rgbd"], mesh=ep["mesh"].expand(len(sel), -1, -1), mask=res["mask"],

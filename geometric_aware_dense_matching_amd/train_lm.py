@@ -8,9 +8,16 @@ SyncBN + DDP over RCCL.  Launch as the reference does (train_lm.sh:8), e.g.
     python -m torch.distributed.run --nproc_per_node=8 -m geometric_aware_dense_matching_amd.train_lm \\
         --gpus=8 -state=train -dataset_name=lmo -cls_id=1 -checkpoint=train_log/lm/checkpoints/
 
-Two things differ by design:
+`-dataset_name {lmo,ycbv}` selects the configuration the reference imports at module top (config/<name>_cfg.py:
+diameters, neighbour radius factor, key-point and checkpoint directories, object list, batch sizes, strict / non-strict
+checkpoint loading); `--model-variant dgcnn` builds models/geoMatch_DGCNN.py's GeoMatch instead of the FFB6D + SplineCNN one.
+
+Three things differ by design:
   * the neighbour pyramid is built on the GPU inside `model_fn_dec` (two launches per batch) instead of 22
     KD-tree calls per crop in the DataLoader workers;
+  * `test()` keeps one model per object of the dataset like the reference (train_lm.py:331-340) but runs the instances of a
+    batch GROUPED per object (infer.run_multi_object) instead of one batch-1 forward per instance (:298-314), with the
+    input-independent mesh descriptors cached per object;
   * BOP dataset loaders are out of scope: `-data synthetic` (default) feeds generated crops
     with the loader's item layout, a real loader can be plugged through `--dataset-factory module:function`.
 """
@@ -23,14 +30,14 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import matching, pose, pyramid, synthetic
+from . import infer, matching, pose, pyramid, synthetic
 from .checkpoint import load_checkpoint, save_checkpoint
-from .config import LM_DIAMETERS, make_model_cfg
+from .config import LMO_OBJS as LM_OBJS, dataset_config, make_dgcnn_cfg, make_model_cfg
 from .geoMatch import GeoMatch
 from .parallel import init_distributed, wrap_for_training
 
-LM_OBJS = {1: "ape", 5: "can", 6: "cat", 8: "driller", 9: "duck", 10: "eggbox", 11: "glue", 12: "holepuncher"}
 bnm_clip = 1e-2
+DEFAULT_DATASET = "lmo"                     # train_ycb.py sets "ycbv" (train_ycb.py:70)
 
 
 def build_parser():
@@ -43,7 +50,7 @@ def build_parser():
     p.add_argument("-bn_decay", type=float, default=0.5)
     p.add_argument("-checkpoint", type=str, default=None)
     p.add_argument("-state", type=str, default="eval")
-    p.add_argument("-dataset_name", type=str, default="lmo")
+    p.add_argument("-dataset_name", type=str, default=DEFAULT_DATASET)
     p.add_argument("-cls_id", type=int, default=5)
     p.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     p.add_argument("-n", "--nodes", default=1, type=int)
@@ -54,18 +61,27 @@ def build_parser():
     # additions (not in the reference)
     p.add_argument("-data", type=str, default="synthetic")
     p.add_argument("--dataset-factory", type=str, default=None, help="module:function(cfg, split) -> torch Dataset")
+    p.add_argument("--model-variant", type=str, default="ffb6d", choices=["ffb6d", "dgcnn"],
+                   help="ffb6d = models/geoMatch.py (CNN + RandLA + SplineCNN); dgcnn = models/geoMatch_DGCNN.py")
     p.add_argument("--epochs", type=int, default=50)
-    p.add_argument("--batch-size", type=int, default=24)
+    p.add_argument("--batch-size", type=int, default=None, help="default: the dataset's TRAIN_BATCH_SIZE / VAL_BATCH_SIZE")
     p.add_argument("--n-points", type=int, default=4096)
     p.add_argument("--n-mesh", type=int, default=4096)
     p.add_argument("--synthetic-items", type=int, default=256)
-    p.add_argument("--log-dir", type=str, default="train_log/lm/checkpoints")
+    p.add_argument("--log-dir", type=str, default=None, help="default: the dataset's checkpoint directory")
     p.add_argument("--save-every", type=int, default=10)
+    p.add_argument("--log-every", type=int, default=100)
+    p.add_argument("--max-iters", type=int, default=None)
+    p.add_argument("--single-object", action="store_true", help="test: only -cls_id instead of every object of the dataset")
+    p.add_argument("--graph-batch1", action="store_true",
+                   help="test: per-object hipGraph replay for single-instance groups (a batch-1 eager step is launch-bound)")
     return p
 
 
 class BNMomentumScheduler:
-    """models/pytorch_utils.py:486-505."""
+    """models/pytorch_utils.py:486-505.  As in the reference the setter matches BatchNorm1d/2d/3d only (:478-481): the reference
+    converts to SyncBatchNorm BEFORE it builds the scheduler (train_lm.py:412,449-457), so under DDP the SyncBN layers keep their
+    constructor momentum (0.1; 0.99 for RandLA's layers) and only single-process runs see the decay."""
 
     def __init__(self, model, bn_lambda, last_epoch=-1):
         self.model, self.lmbd = model, bn_lambda
@@ -78,7 +94,7 @@ class BNMomentumScheduler:
         self.last_epoch = epoch
         m = self.lmbd(epoch)
         for mod in self.model.modules():
-            if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm)):
+            if type(mod) in (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d):
                 mod.momentum = m
 
 
@@ -86,8 +102,9 @@ class SyntheticCrops(torch.utils.data.Dataset):
     """Generated items with the loader's keys (datasets/lm/linemod_pbr.py:572-599): model inputs + labels,
     match_idx (index of the corresponding model vertex, M = 'no correspondence'), visible_flag, RT."""
 
-    def __init__(self, n_items, n_points, n_mesh, seed=0):
+    def __init__(self, n_items, n_points, n_mesh, seed=0, cls_ids=None):
         self.n_items, self.n_points, self.n_mesh, self.seed = n_items, n_points, n_mesh, seed
+        self.cls_ids = list(cls_ids) if cls_ids else None          # test split: item i is an instance of cls_ids[i % len]
 
     def __len__(self):
         return self.n_items
@@ -98,8 +115,10 @@ class SyntheticCrops(torch.utils.data.Dataset):
         labels = it["labels"].astype(np.int32)
         match = rs.randint(0, self.n_mesh, size=self.n_points).astype(np.int32)
         match[rs.rand(self.n_points) < 0.1] = self.n_mesh
-        it.update(labels=labels, match_idx=match, visible_flag=(rs.rand(self.n_mesh) < 0.6).astype(np.uint8),
+        it.update(labels=labels, origin_labels=labels.copy(), match_idx=match, visible_flag=(rs.rand(self.n_mesh) < 0.6).astype(np.uint8),
                   RT=np.eye(4, dtype=np.float32)[:3])
+        if self.cls_ids:
+            it["cls_id"] = np.int32(self.cls_ids[i % len(self.cls_ids)])
         return it
 
 
@@ -123,7 +142,8 @@ def to_device(data, device):
 
 def model_fn_dec(model, data, device):
     cu = to_device(data, device)
-    if "cld_nei_idx0" not in cu:                              # pyramid on the GPU (two launches per batch)
+    needs_pyramid = getattr(getattr(model, "module", model), "needs_pyramid", True)       # the DGCNN variant builds its own graphs
+    if needs_pyramid and "cld_nei_idx0" not in cu:            # pyramid on the GPU (two launches per batch)
         cu.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(cu["cld_rgb_nrm"]), cu["dpt_xyz"]))
     return model(cu), cu
 
@@ -140,105 +160,149 @@ class Trainer:
         self.history = []
 
     def train(self, start_epoch, n_epochs, train_loader, train_sampler=None, max_iters=None):
+        """train_lm.py:224-296.  The reference reads three `.item()`s per iteration (:271-273), i.e. three device syncs; here the
+        running sums stay on the device and are read once per `log_every` iterations (and once at the end for `history`)."""
         it_total = 0
-        for epoch in range(start_epoch, n_epochs):
-            if train_sampler is not None:
-                train_sampler.set_epoch(epoch)
-            sums = np.zeros(3)
-            t0 = time.time()
-            for it, batch in enumerate(train_loader):
-                self.model.train()
-                out, _ = model_fn_dec(self.model, batch, self.device)
-                loss = out["loss"]
-                vals = (loss.item(), out["seg_loss"].item(), float(out["match_loss"].detach()))
-                sums += vals
-                self.history.append(vals)
-                if (it + 1) % self.log_every == 0 and self.local_rank == 0:
-                    print("avg_loss:{:.4f} seg: {:.4f} match: {:.4f}  time cost:{:.1f} s".format(
-                        *(sums / self.log_every), time.time() - t0))
-                    sums[:] = 0
-                    t0 = time.time()
-                loss.backward()
-                self.optimizer.step()
-                self.optimizer.zero_grad()
-                if self.lr_scheduler is not None:
-                    self.lr_scheduler.step()
-                if self.bnm_scheduler is not None:
-                    self.bnm_scheduler.step()
-                it_total += 1
-                if max_iters is not None and it_total >= max_iters:
-                    return it_total
-            if (epoch + 1) % self.save_every == 0 and self.local_rank == 0:
-                save_checkpoint(self.model, self.optimizer, epoch, self.checkpoint_dir, self.obj_name)
-        return it_total
+        dev_hist = []
+        try:
+            for epoch in range(start_epoch, n_epochs):
+                if train_sampler is not None:
+                    train_sampler.set_epoch(epoch)
+                sums = None
+                t0 = time.time()
+                for it, batch in enumerate(train_loader):
+                    self.model.train()
+                    out, _ = model_fn_dec(self.model, batch, self.device)
+                    loss = out["loss"]
+                    vals = torch.stack([loss.detach().float(), out["seg_loss"].detach().float(),
+                                        torch.as_tensor(out["match_loss"], device=loss.device).detach().float()])
+                    sums = vals if sums is None else sums + vals
+                    dev_hist.append(vals)
+                    if (it + 1) % self.log_every == 0:
+                        if self.local_rank == 0:
+                            print("avg_loss:{:.4f} seg: {:.4f} match: {:.4f}  time cost:{:.1f} s".format(
+                                *(sums / self.log_every).tolist(), time.time() - t0))
+                        sums = None
+                        t0 = time.time()
+                    loss.backward()
+                    self.optimizer.step()
+                    self.optimizer.zero_grad()
+                    if self.lr_scheduler is not None:
+                        self.lr_scheduler.step()
+                    if self.bnm_scheduler is not None:
+                        self.bnm_scheduler.step()
+                    it_total += 1
+                    if max_iters is not None and it_total >= max_iters:
+                        return it_total
+                if (epoch + 1) % self.save_every == 0 and self.local_rank == 0:
+                    save_checkpoint(self.model, self.optimizer, epoch, self.checkpoint_dir, self.obj_name)
+            return it_total
+        finally:
+            if dev_hist:
+                self.history += [tuple(v) for v in torch.stack(dev_hist).cpu().tolist()]
 
 
-def make_dataset(args, split):
+def make_dataset(args, split, cls_ids=None):
     if args.dataset_factory:
         mod, fn = args.dataset_factory.split(":")
         return getattr(importlib.import_module(mod), fn)(args, split)
-    return SyntheticCrops(args.synthetic_items, args.n_points, args.n_mesh, seed=0 if split == "train" else 1)
+    return SyntheticCrops(args.synthetic_items, args.n_points, args.n_mesh, seed=0 if split == "train" else 1, cls_ids=cls_ids)
 
 
-def _model_points(args, cls_id):
-    path = os.path.join("datasets/lm/linemod/kps", "obj_%06d_fps.npy" % cls_id)
+def _model_points(args, ds, cls_id):
+    path = os.path.join(ds["model_pth"], "obj_%06d_fps.npy" % cls_id)
     if os.path.exists(path):
         return np.load(path)
-    return synthetic.make_model_points(cls_id, args.n_mesh, LM_DIAMETERS.get(cls_id, 100.0))
+    return synthetic.make_model_points(cls_id, args.n_mesh, ds["diameters"][cls_id])       # KeyError: not an object of this dataset
+
+
+def build_model(args, cls_id, cache_mesh_in_eval=False):
+    """GeoMatch(cfg.MODEL, cls_id) of the selected dataset and variant (train_lm.py:410, :332)."""
+    ds = dataset_config(args.dataset_name)
+    if cls_id not in ds["diameters"]:
+        raise KeyError("-cls_id=%d is not an object of -dataset_name=%s (ids %s)" % (cls_id, args.dataset_name, sorted(ds["diameters"])))
+    pts = _model_points(args, ds, cls_id)
+    if args.model_variant == "dgcnn":
+        from .geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
+        return GeoMatchDGCNN(make_dgcnn_cfg(n_mesh_node=args.n_mesh, dataset=args.dataset_name), cls_id, model_points=pts)
+    cfg = make_model_cfg(n_mesh_node=args.n_mesh, num_points=args.n_points, dataset=args.dataset_name)
+    return GeoMatch(cfg, cls_id, model_points=pts, cache_mesh_in_eval=cache_mesh_in_eval)
+
+
+def obj_name_of(ds, cls_id):
+    return ds["objs"].get(cls_id, "obj_%02d" % cls_id)
 
 
 def train(args):
     torch.backends.cudnn.benchmark = not args.deterministic
-    if args.deterministic:
+    if args.deterministic:                                    # train_lm.py:377-381
+        torch.backends.cudnn.deterministic = True
         torch.manual_seed(args.local_rank)
+    ds = dataset_config(args.dataset_name)
+    batch_size = args.batch_size or ds["train_batch_size"]
+    log_dir = args.log_dir or ds["checkpoints"]
     device = torch.device("cuda", args.local_rank)
     torch.cuda.set_device(device)
     rank, local_rank, world = init_distributed("nccl", device)
     train_ds = make_dataset(args, "train")
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds) if world > 1 else None
-    loader = torch.utils.data.DataLoader(train_ds, batch_size=args.batch_size, shuffle=sampler is None, drop_last=True,
+    loader = torch.utils.data.DataLoader(train_ds, batch_size=batch_size, shuffle=sampler is None, drop_last=True,
                                          num_workers=4, sampler=sampler)
-    cfg = make_model_cfg(n_mesh_node=args.n_mesh, num_points=args.n_points)
-    model = GeoMatch(cfg, args.cls_id, model_points=_model_points(args, args.cls_id)).to(device)
+    model = build_model(args, args.cls_id).to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.0001, weight_decay=args.weight_decay)
     it, start_epoch = -1, 0
-    obj_name = LM_OBJS.get(args.cls_id, "obj_%02d" % args.cls_id)
+    obj_name = obj_name_of(ds, args.cls_id)
     if args.checkpoint is not None:
-        ep = load_checkpoint(model, optimizer, os.path.join(args.checkpoint, obj_name, "geomatch"), device=device)
+        ep = load_checkpoint(model, optimizer, os.path.join(args.checkpoint, obj_name, "geomatch"), device=device, strict=ds["load_strict"])
         if ep is not None:
             start_epoch = ep
     model = wrap_for_training(model, local_rank)
-    steps = max(1, args.epochs * len(train_ds) // args.batch_size // 6 // max(world, 1))
+    steps = max(1, args.epochs * len(train_ds) // batch_size // 6 // max(world, 1))
     lr_scheduler = torch.optim.lr_scheduler.CyclicLR(optimizer, base_lr=1e-6, max_lr=1e-3, cycle_momentum=False,
                                                      step_size_up=steps, step_size_down=steps, mode="triangular")
-    bnm = BNMomentumScheduler(model, lambda i: max(args.bn_momentum * args.bn_decay ** int(i * args.batch_size / args.decay_step),
+    bnm = BNMomentumScheduler(model, lambda i: max(args.bn_momentum * args.bn_decay ** int(i * batch_size / args.decay_step),
                                                    bnm_clip), last_epoch=it)
-    trainer = Trainer(model, optimizer, args.log_dir, obj_name, lr_scheduler, bnm, device, local_rank, args.save_every)
-    trainer.train(start_epoch, args.epochs, loader, sampler)
+    trainer = Trainer(model, optimizer, log_dir, obj_name, lr_scheduler, bnm, device, local_rank, args.save_every, args.log_every)
+    trainer.train(start_epoch, args.epochs, loader, sampler, max_iters=args.max_iters)
+    return trainer
 
 
 def test(args):
-    """train_lm.py:317-373 without the BOP evaluator: per-object models, batched forward (crops grouped by
-    object instead of batch-1 per instance, :298-314) and dense matching; returns the correspondences."""
+    """train_lm.py:317-373 without the BOP evaluator: ONE MODEL PER OBJECT of the dataset (:331-340), every batch dispatched per
+    instance by its `cls_id` (:298-314) -- grouped per object into true batches here -- then dense matching and the batched GPU
+    pose solve (evaluator.py:78-100).  Returns per-batch results in the loader's instance order."""
+    ds = dataset_config(args.dataset_name)
+    batch_size = args.batch_size or ds["val_batch_size"]
     device = torch.device("cuda", args.local_rank)
     torch.cuda.set_device(device)
-    cfg = make_model_cfg(n_mesh_node=args.n_mesh, num_points=args.n_points)
-    model = GeoMatch(cfg, args.cls_id, model_points=_model_points(args, args.cls_id), cache_mesh_in_eval=True).to(device)
-    if args.checkpoint is not None:
-        load_checkpoint(model, None, os.path.join(args.checkpoint, LM_OBJS.get(args.cls_id, "obj_%02d" % args.cls_id), "geomatch"),
-                        device=device)
-    model.eval()
-    loader = torch.utils.data.DataLoader(make_dataset(args, "test"), batch_size=args.batch_size, shuffle=False, num_workers=2)
+    ids = [args.cls_id] if args.single_object else sorted(ds["objs"])
+    ckpt_root = args.checkpoint or ds["checkpoints"]
+    model_dict = {}
+    for cid in ids:
+        model = build_model(args, cid, cache_mesh_in_eval=True).to(device)
+        stem = os.path.join(ckpt_root, obj_name_of(ds, cid), "geomatch")
+        if os.path.exists(stem + ".pth.tar"):                 # the reference also skips objects without a checkpoint (:336)
+            load_checkpoint(model, None, stem, device=device, strict=ds["load_strict"])
+        model_dict[cid] = model.eval()
+    loader = torch.utils.data.DataLoader(make_dataset(args, "test", cls_ids=ids), batch_size=batch_size, shuffle=False, num_workers=2)
+    graphs = {}
     results = []
     with torch.no_grad():
         for batch in loader:
             t0 = time.perf_counter()
-            ep, cu = model_fn_dec(model, batch, device)
-            res = matching.match_frames(ep)
-            RT, valid = pose.solve_poses(res, cu["cld_rgb_nrm"], model.model_emb.xyz)        # evaluator.py:94-100, batched on the GPU
+            cu = to_device(batch, device)
+            cls = cu["cls_id"].cpu().tolist() if "cls_id" in cu else [args.cls_id] * cu["cld_rgb_nrm"].shape[0]
+            if args.graph_batch1 and args.model_variant == "ffb6d" and len(cls) == 1:
+                cid = cls[0]
+                one = {k: cu[k] for k in ("rgb", "cld_rgb_nrm", "choose", "dpt_xyz")}
+                if cid not in graphs:
+                    graphs[cid] = infer.GraphedPipeline(model_dict[cid], one)
+                out = {k: v.clone() for k, v in graphs[cid](one).items()}
+            else:
+                out = infer.run_multi_object(model_dict, cu, cls)
             torch.cuda.synchronize()
-            results.append(dict(time=time.perf_counter() - t0, count=res["count"].cpu(), best_idx=res["best_idx"].cpu(),
-                                best_sim=res["best_sim"].cpu(), mask=res["mask"].cpu(), RT=RT.cpu(), valid=valid.cpu()))
+            results.append(dict(time=time.perf_counter() - t0, cls_id=cls, count=out["mask"].sum(dim=1).cpu(), best_idx=out["best_idx"].cpu(),
+                                best_sim=out["best_sim"].cpu(), mask=out["mask"].cpu(), RT=out["RT"].cpu(), valid=out["valid"].cpu()))
     return results
 
 

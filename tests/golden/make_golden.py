@@ -22,6 +22,7 @@ produced by importing / compiling the reference's code here:
   losses.npz             reference CircleLoss / FocalLoss / AutomaticWeightedLoss /
                          pointwise_feature_matching (training matching path) values and grads
   matching.npz           evaluator.py:79-93 executed from the mounted reference tree
+  dataset_configs.json   the keys of config/{lmo,ycbv}_cfg.py that -dataset_name selects (diameters, radius factor, paths, ...)
 
 Reference modules are imported with empty stand-in modules for third-party packages that are
 absent here and unused on this path (cv2, normalSpeed, plyfile, torch_geometric, ...).  The
@@ -461,6 +462,17 @@ def main():
         adds.append(env["add"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
         adis.append(env["adi"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
     np.savez_compressed(os.path.join(HERE, "pose.npz"), RT=np.stack(poses), add=np.array(adds), adi=np.array(adis))
+    # ------------------------------------------------------------------ dataset configurations the entry points select by -dataset_name
+    import importlib
+    cfgs = {}
+    for name in ("lmo", "ycbv"):             # lmfull_cfg.py is stale (no model_d / neighbor_dis_th) and imported by no entry point
+        c = importlib.import_module("config.%s_cfg" % name)
+        cfgs[name] = dict(diameters={str(k): v for k, v in c.MODEL["model_d"].items()}, neighbor_dis_th=c.MODEL["neighbor_dis_th"],
+                          model_pth=c.MODEL["model_pth"], checkpoints=c.MODEL["checkpoints"], model_name=c.MODEL["model_name"],
+                          objs={str(k): v for k, v in c.DATASETS["OBJS"].items()}, sym_objs=list(c.DATASETS["SYM_OBJS"]),
+                          train_batch_size=c.DATALOADER["TRAIN_BATCH_SIZE"], val_batch_size=c.DATALOADER["VAL_BATCH_SIZE"],
+                          n_points=c.DATASETS["NUM_SAMPLE_POINTS"], n_mesh=c.DATASETS["MODEL_PT_NUM"], feat_dim=c.MODEL["feat_dim"])
+    json.dump(cfgs, open(os.path.join(HERE, "dataset_configs.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         print("  %-24s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -97,10 +97,41 @@ def test_trainer_runs_saves_and_resumes(tmp_path):
 
 def test_test_entry_point_runs():
     from geometric_aware_dense_matching_amd import train_lm
-    args = train_lm.build_parser().parse_args("--gpus=0 -state=test -cls_id=1 --batch-size 2 --n-points 1024 --n-mesh 512 "
+    args = train_lm.build_parser().parse_args("--gpus=0 -state=test -cls_id=1 --single-object --batch-size 2 --n-points 1024 --n-mesh 512 "
                                               "--synthetic-items 4".split())
     res = train_lm.test(args)
     assert len(res) == 2 and res[0]["best_idx"].shape == (2, 1024) and int(res[0]["best_idx"].max()) < 512
+
+
+@pytest.mark.parametrize("entry,cls_id,extra", [("train_lm", 5, ""), ("train_ycb", 21, ""), ("train_ycb", 16, "--model-variant dgcnn")])
+def test_entry_points_train_then_multi_object_test_per_dataset_and_variant(tmp_path, entry, cls_id, extra):
+    """BASELINE configs 3 / 4 / 5 surfaces: `-state=train` (one epoch of two iterations, checkpoint written in the reference's
+    layout under the dataset's object name) then `-state=test` with ONE MODEL PER OBJECT of the dataset (8 LM-O / 21 YCB-V,
+    train_lm.py:331-340), instances dispatched by cls_id, matching + pose; the trained object's checkpoint is the one loaded."""
+    import importlib
+    from geometric_aware_dense_matching_amd import config, train_lm
+    mod = importlib.import_module("geometric_aware_dense_matching_amd." + entry)
+    common = "--n-points 1024 --n-mesh 256 --synthetic-items 4 %s" % extra
+    a = mod.build_parser().parse_args(("-state=train -cls_id=%d --deterministic --batch-size 2 --epochs 1 --save-every 1 --log-every 1 --log-dir %s %s"
+                                       % (cls_id, tmp_path, common)).split())
+    ds = config.dataset_config(a.dataset_name)
+    trainer = train_lm.train(a)
+    assert len(trainer.history) == 2 and all(np.isfinite(h).all() for h in trainer.history)
+    name = ds["objs"][cls_id]
+    assert os.path.exists(os.path.join(str(tmp_path), name, "geomatch.pth.tar"))
+    trained = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
+    t = mod.build_parser().parse_args(("-state=test -cls_id=%d -checkpoint %s --batch-size 4 %s" % (cls_id, tmp_path, common)).split())
+    res = train_lm.test(t)
+    n_obj = len(ds["objs"])
+    assert n_obj == (8 if a.dataset_name == "lmo" else 21)
+    assert len(res) == 1 and res[0]["best_idx"].shape == (4, 1024) and res[0]["RT"].shape == (4, 3, 4)
+    assert res[0]["cls_id"] == sorted(ds["objs"])[:4] and int(res[0]["best_idx"].max()) < 256
+    # the multi-object driver equals a per-instance pass through that instance's own model (the reference's dispatch)
+    model = train_lm.build_model(t, cls_id, cache_mesh_in_eval=True).cuda()
+    from geometric_aware_dense_matching_amd.checkpoint import load_checkpoint
+    assert load_checkpoint(model, None, os.path.join(str(tmp_path), name, "geomatch"), device="cuda", strict=ds["load_strict"]) == 0
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, trained[k]), k
 
 
 def test_prelu1_forward_backward_equals_torch():

@@ -148,3 +148,41 @@ def test_summarize_trace_windows(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_trace.py"), str(tmp_path / "t.csv"), "--steps", "5",
                           "--periodic"], capture_output=True, text=True, check=True).stdout
     assert "5 steps" in out.splitlines()[0] and "5 kernels/step" in out.splitlines()[0]
+
+
+def test_dataset_configs_match_the_reference_config_modules():
+    """-dataset_name selects what the reference imports as config/<name>_cfg.py: 15 LineMOD / 21 YCB-V diameters, the neighbour
+    radius factor (0.02 / 0.06), directories, object lists, batch sizes (golden: tests/golden/dataset_configs.json, dumped from
+    the imported reference modules); positive_r = neighbor_dis_th * diameter / 1000 (geoMatch.py:26)."""
+    import json
+    from geometric_aware_dense_matching_amd import config
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dataset_configs.json")))
+    assert set(gold) == set(config.DATASET_CONFIGS) == {"lmo", "ycbv"}
+    for name, g in gold.items():
+        c = config.dataset_config(name)
+        assert {str(k): v for k, v in c["diameters"].items()} == g["diameters"]
+        assert {str(k): v for k, v in c["objs"].items()} == g["objs"]
+        for k in ("neighbor_dis_th", "model_pth", "checkpoints", "model_name", "train_batch_size", "val_batch_size", "n_points", "n_mesh"):
+            assert c[k] == g[k], (name, k)
+        assert list(c["sym_objs"]) == g["sym_objs"]
+        m = config.make_model_cfg(dataset=name)
+        assert m["neighbor_dis_th"] == g["neighbor_dis_th"] and m["model_name"] == g["model_name"] and m["feat_dim"] == g["feat_dim"]
+    assert len(gold["ycbv"]["diameters"]) == 21 and len(gold["lmo"]["diameters"]) == 15
+    with pytest.raises(KeyError):
+        config.dataset_config("tless")
+
+
+def test_entry_points_select_dataset_and_variant():
+    from geometric_aware_dense_matching_amd import train_lm, train_ycb
+    a = train_lm.build_parser().parse_args("-state=train -cls_id=1".split())
+    assert a.dataset_name == "lmo" and a.model_variant == "ffb6d" and a.batch_size is None
+    b = train_ycb.build_parser().parse_args("-state=train -cls_id=21 --model-variant dgcnn".split())
+    assert b.dataset_name == "ycbv" and b.model_variant == "dgcnn"
+    m = train_lm.build_model(train_ycb.build_parser().parse_args("-cls_id=21 --n-mesh 64 --n-points 1024".split()), 21)
+    assert abs(m.positive_r - 0.06 * 102.903 / 1000.0) < 1e-12                 # ycbv_cfg.py:25,134; geoMatch.py:26
+    m = train_lm.build_model(train_lm.build_parser().parse_args("-cls_id=1 --n-mesh 64 --n-points 1024".split()), 1)
+    assert abs(m.positive_r - 0.02 * 102.099 / 1000.0) < 1e-12
+    with pytest.raises(KeyError):
+        train_lm.build_model(train_lm.build_parser().parse_args("-cls_id=16 --n-mesh 64".split()), 16)   # not a LineMOD object
+    d = train_lm.build_model(train_ycb.build_parser().parse_args("-cls_id=16 --n-mesh 64 --model-variant dgcnn".split()), 16)
+    assert type(d).__module__.endswith("geoMatch_DGCNN") and d.needs_pyramid is False
