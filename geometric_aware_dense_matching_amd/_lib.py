@@ -60,6 +60,14 @@ SIGNATURES = {
     "gdm_edge_feature_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_circle_rows_fwd_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "gdm_circle_rows_bwd_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "gdm_circle_match_rows_bytes": (_sz, [_i]),
+    "gdm_circle_match_tp_bytes": (_sz, [_i]),
+    "gdm_circle_match_pack_hip": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "gdm_circle_match_nbr_hip": (_i, [_vp, _i, _f, _vp, _vp]),
+    "gdm_circle_match_visbits_hip": (_i, [_vp, _i, _i, _vp, _vp]),
+    "gdm_circle_match_fwd_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "gdm_circle_match_bwd_parts": (_i, [_i, _i]),
+    "gdm_circle_match_bwd_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gdm_kabsch_stats_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "gdm_kabsch_solve_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gdm_lfa_stage_hip": (_i, [_vp] * 13 + [_i, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -42,47 +42,33 @@ class GeoMatch(nn.Module):
         self.normalize_feature_layer = pt_conv1d(self.feat_dim, self.feat_dim, bn=True)
 
         self.cache_mesh_in_eval = cache_mesh_in_eval
-        self.fused_loss = True          # False: the reference's per-item loop in plain torch (kept for A/B checks)
         self._mesh_cache = None
 
     # ------------------------------------------------------------------ training matching (geoMatch.py:55-157)
-    def matching_loss(self, similarity, match_idx, mesh_xyz, vis_flag, RT):
-        n_node = len(mesh_xyz)
-        dev = similarity.device
-        idx_in_mesh = match_idx != n_node
-        idx_mesh_in = torch.where(match_idx != n_node)[0]
-        idx_out_mesh = match_idx == n_node
-        gt_pt = mesh_xyz[match_idx[idx_in_mesh]]
-        vis = vis_flag.to(torch.bool)
-        dis_matrix = pdist(gt_pt, mesh_xyz[vis])
-        pts_num, cols = similarity.shape
-        p_n_mask = torch.zeros((pts_num, cols - 1), dtype=torch.bool, device=dev)
-        p_n_in_mesh = torch.index_select(p_n_mask, 0, idx_mesh_in)
-        p_n_in_mesh[:, vis] = dis_matrix < self.positive_r
-        p_n_mask[idx_in_mesh] = p_n_in_mesh
-        p_n_mask = torch.cat([p_n_mask, idx_out_mesh.unsqueeze(1)], dim=1)
-        return self.circle_loss(similarity, p_n_mask, 0.2)
-
-    def matching_loss_sys(self, similarity, match_idx, idxs):
-        sys_cor = self.model_emb.sys_idx
-        pts_num, vert_num = similarity.shape
-        cld_idx = torch.arange(pts_num, device=similarity.device)
-        cld_idx = torch.cat((cld_idx, cld_idx), dim=0)
-        selected_idx = torch.cat((match_idx[idxs], match_idx[sys_cor[idxs]]), dim=0)
-        p_n_mask = torch.zeros((pts_num, vert_num), dtype=torch.bool, device=similarity.device)
-        p_n_mask[cld_idx, selected_idx] = True
-        return self.circle_loss(similarity, p_n_mask, 0.2)
-
-    def pointwise_feature_matching_fused(self, rgbd_feature, mesh_feature, x):
-        """Same value and gradients as pointwise_feature_matching (non-symmetric objects), batched:
-        one GEMM for all selected points of the batch, then the fused circle-loss rows kernel
-        (ops.circle_rows); no per-item Python loop over [n_i, M+1] temporaries."""
+    def _positive_tables(self, mesh_xyz):
+        """Radius-test bit table of the model (depends on xyz and positive_r only): built once, rebuilt if either changes."""
         from . import ops
-        B = rgbd_feature.shape[0]
+        key = (mesh_xyz.data_ptr(), mesh_xyz._version, float(self.positive_r), mesh_xyz.device)
+        cache = self.__dict__.get("_gdm_nbr")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.circle_nbr_table(mesh_xyz, self.positive_r))
+            self.__dict__["_gdm_nbr"] = cache
+        return cache[1]
+
+    def pointwise_feature_matching(self, rgbd_feature, mesh_feature, x):
+        """geoMatch.py:102-157 for the whole batch at once: value and gradients of the reference's per-item loop (mean over the
+        items with >= 3 selected points of the mean circle loss of their rows).  The [n_sel, M+1] similarity is never formed: unit
+        rows go to ops.circle_match (MFMA similarity tiles, masked LSEs in registers, recomputation in the backward kernels).
+        Non-symmetric objects: positives = visible vertices within positive_r of the ground-truth vertex (:55-83); symmetric
+        objects (model_emb.sys_corr_idx set): the row's own match and the match of its symmetric counterpart (:86-100, indexing
+        restated as the reference writes it).  settings.USE_FUSED_MATCH_LOSS = False: same batch formulation with the similarity
+        materialised by one GEMM (the form the fused kernels are tested against, besides oracle/loss_ref.py and the goldens)."""
+        from . import ops, settings
+        if not rgbd_feature.is_cuda:
+            raise RuntimeError("GeoMatch training matching loss runs on the GPU (HIP kernels); there is no CPU fallback")
+        B, D, N = rgbd_feature.shape
         mesh = mesh_feature[0]
         M = mesh.shape[1]
-        padding = -torch.ones((self.feat_dim, 1), dtype=torch.float32, device=mesh.device)
-        mesh_padded = F.normalize(torch.cat([mesh, padding], dim=1), p=2, dim=0)
         labels = x["labels"]
         sel = labels == 1                                          # [B,N]
         counts = sel.sum(dim=1)
@@ -92,39 +78,39 @@ class GeoMatch(nn.Module):
         if bi.numel() == 0:
             return torch.zeros((), device=mesh.device)
         rows = F.normalize(rgbd_feature.transpose(1, 2)[bi, pi], p=2, dim=1)      # [R,128]
-        sim = torch.matmul(rows, mesh_padded)                      # [R, M+1]
-        match = x["match_idx"][bi, pi]
-        lrow = ops.circle_rows(sim, match, bi, self.model_emb.xyz.contiguous(), x["visible_flag"], self.positive_r, 16.0, 0.2)
+        match_all = x["match_idx"].long()
+        symmetric = self.model_emb.sys_corr_idx is not None
+        if symmetric:
+            if N != M:
+                raise IndexError("symmetric matching loss: the reference indexes the per-vertex symmetry table with point indices and "
+                                 "the per-point match table with its entries (geoMatch.py:91-93), which needs N == M (got %d, %d)" % (N, M))
+            sys_idx = self.model_emb.sys_idx.to(match_all.device).long()
+            c1 = match_all[bi, pi]
+            c2 = match_all[bi, sys_idx[pi]]
+        else:
+            c1, c2 = match_all[bi, pi], None
+        if settings.USE_FUSED_MATCH_LOSS:
+            mesh_rows = F.normalize(mesh, p=2, dim=0).t().contiguous()             # [M,128]; the -1 padding column is analytic
+            if symmetric:
+                lrow = ops.circle_match(rows, mesh_rows, c1, bi, c2=c2, gamma=16.0, m=0.2)
+            else:
+                lrow = ops.circle_match(rows, mesh_rows, c1, bi, nbr=self._positive_tables(self.model_emb.xyz.contiguous()),
+                                        visb=ops.circle_visbits(x["visible_flag"]), gamma=16.0, m=0.2)
+        else:
+            padding = -torch.ones((self.feat_dim, 1), dtype=torch.float32, device=mesh.device)
+            mesh_padded = F.normalize(torch.cat([mesh, padding], dim=1), p=2, dim=0)
+            sim = torch.matmul(rows, mesh_padded)                  # [R, M+1], materialised
+            if symmetric:
+                mask = torch.zeros(sim.shape, dtype=torch.bool, device=sim.device)
+                ar = torch.arange(sim.shape[0], device=sim.device)
+                mask[ar, c1] = True
+                mask[ar, c2] = True
+                lrow = self.circle_loss.rows(sim, mask, 0.2)
+            else:
+                lrow = ops.circle_rows(sim, c1, bi, self.model_emb.xyz.contiguous(), x["visible_flag"], self.positive_r, 16.0, 0.2)
         per_item = torch.zeros(B, dtype=torch.float32, device=mesh.device).index_add_(0, bi, lrow)
         per_item = per_item[item_ok] / counts[item_ok].to(torch.float32)
         return per_item.mean()
-
-    def pointwise_feature_matching(self, rgbd_feature, mesh_feature, x):
-        if self.model_emb.sys_corr_idx is None and rgbd_feature.is_cuda and self.fused_loss:
-            return self.pointwise_feature_matching_fused(rgbd_feature, mesh_feature, x)
-        match_loss = []
-        batch = rgbd_feature.shape[0]
-        rgbd_feature = rgbd_feature.transpose(1, 2)
-        mesh = mesh_feature[0]
-        padding = -torch.ones((self.feat_dim, 1), dtype=torch.float32, device=mesh.device)
-        mesh_padded = F.normalize(torch.cat([mesh, padding], dim=1), p=2, dim=0)
-        labels, corr, RTs = x["labels"], x["match_idx"], x["RT"]
-        for i in range(batch):
-            idxs = torch.where(labels[i] == 1)[0]
-            if len(idxs) < 3:
-                continue
-            selected_cld = F.normalize(rgbd_feature[i].index_select(0, idxs), p=2, dim=1)
-            selected_corr = corr[i].index_select(0, idxs)
-            similarity = torch.matmul(selected_cld, mesh_padded)
-            if self.model_emb.sys_corr_idx is not None:
-                li = self.matching_loss_sys(similarity, corr[i].long(), idxs)
-            else:
-                li = self.matching_loss(similarity, selected_corr.long(), self.model_emb.xyz.contiguous(),
-                                        x["visible_flag"][i], RTs[i])
-            match_loss.append(li)
-        if len(match_loss) == 0:
-            return torch.zeros((), device=mesh.device)
-        return torch.mean(torch.stack(match_loss))
 
     # ------------------------------------------------------------------ forward (geoMatch.py:159-200)
     def mesh_features(self):

@@ -44,7 +44,8 @@ class CircleLoss(nn.Module):
         off = (inputs - s).masked_fill(inv.to(torch.bool), -float("inf"))
         return (s + off.exp().sum(dim=-1, keepdim=True).log()).squeeze(-1)
 
-    def forward(self, sim, mask, m):
+    def rows(self, sim, mask, m):
+        """Per-row loss f32[rows] (forward() is its mean)."""
         ap = torch.clamp_min(-sim.detach() + 1 + m, min=0.0).masked_fill(~mask, 0)
         an = torch.clamp_min(sim.detach() + m, min=0.0).masked_fill(mask, 0)
         delta_p, delta_n = 1 - m, m
@@ -52,7 +53,10 @@ class CircleLoss(nn.Module):
         logit_n = an * (sim - delta_n) * self.gamma
         lse_p = self.log_sum_exp(logit_p, mask.to(torch.float))
         lse_n = self.log_sum_exp(logit_n, (~mask).to(torch.float))
-        return self.soft_plus(lse_p + lse_n).mean()
+        return self.soft_plus(lse_p + lse_n)
+
+    def forward(self, sim, mask, m):
+        return self.rows(sim, mask, m).mean()
 
 
 class AutomaticWeightedLoss(nn.Module):

@@ -356,6 +356,108 @@ def circle_rows(sim, match, item, xyz, vis, radius, gamma=16.0, m=0.2):
     return _CircleRows.apply(sim, match, item, xyz, vis8, float(radius), float(gamma), float(m))
 
 
+# --------------------------------------------------------------------------------------
+# training matching loss without the similarity matrix (gdm_circle.hip)
+# --------------------------------------------------------------------------------------
+def circle_nbr_table(xyz, radius):
+    """Bit table u32[M, ceil(M/32)]: vertices within `radius` of each vertex (the reference's pdist arithmetic).  Depends on the
+    model only: build once per (xyz, radius) and reuse."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    M = xyz.shape[0]
+    nbr = torch.empty((M, (M + 31) // 32), dtype=torch.int32, device=xyz.device)
+    check(_lib.lib().gdm_circle_match_nbr_hip(xyz.data_ptr(), M, float(radius), nbr.data_ptr(), _stream()), "gdm_circle_match_nbr_hip")
+    return nbr
+
+
+def circle_visbits(vis):
+    """visible_flag (any dtype, nonzero = visible) [B,M] -> bits i32[B, ceil(M/32)]."""
+    if not vis.is_cuda:
+        raise RuntimeError("vis must be a CUDA (HIP) tensor: the geoMatch ops have no CPU fallback")
+    v8 = (vis != 0).to(torch.uint8).contiguous()
+    B, M = v8.shape
+    bits = torch.empty((B, (M + 31) // 32), dtype=torch.int32, device=vis.device)
+    check(_lib.lib().gdm_circle_match_visbits_hip(v8.data_ptr(), B, M, bits.data_ptr(), _stream()), "gdm_circle_match_visbits_hip")
+    return bits
+
+
+def _cm_pack(x):
+    L = _lib.lib()
+    n = x.shape[0]
+    npad = (n + 127) // 128 * 128
+    rows = torch.empty(L.gdm_circle_match_rows_bytes(n), dtype=torch.uint8, device=x.device)
+    tp = torch.empty(L.gdm_circle_match_tp_bytes(n), dtype=torch.uint8, device=x.device)
+    rsum = torch.empty(npad, dtype=torch.float32, device=x.device)
+    check(L.gdm_circle_match_pack_hip(x.data_ptr(), n, rows.data_ptr(), tp.data_ptr(), rsum.data_ptr(), _stream()), "gdm_circle_match_pack_hip")
+    return rows, tp, rsum
+
+
+def _pad_rows(t, npad, fill):
+    if t.shape[0] == npad:
+        return t.contiguous()
+    out = torch.full((npad,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
+    out[: t.shape[0]] = t
+    return out
+
+
+class _CircleMatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, g, c2, item, nbr, visb, gamma, m):
+        x = _dev(x, torch.float32, "x")
+        y = _dev(y, torch.float32, "y")
+        R, M = x.shape[0], y.shape[0]
+        assert x.shape[1] == 128 and y.shape[1] == 128, "descriptors must have 128 channels"
+        Rp = (R + 127) // 128 * 128
+        xr, xt, xs = _cm_pack(x)
+        yr, yt, _ = _cm_pack(y)
+        gp = _pad_rows(g, Rp, M)
+        ip = _pad_rows(item, Rp, 0)
+        c2p = _pad_rows(c2, Rp, -1) if c2 is not None else None
+        lp = torch.empty(Rp, dtype=torch.float32, device=x.device)
+        ln = torch.empty_like(lp)
+        loss = torch.empty_like(lp)
+        check(_lib.lib().gdm_circle_match_fwd_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M,
+                                                  gp.data_ptr(), c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
+                                                  nbr.data_ptr() if nbr is not None else None, visb.data_ptr() if visb is not None else None,
+                                                  gamma, m, lp.data_ptr(), ln.data_ptr(), loss.data_ptr(), _stream()), "gdm_circle_match_fwd_hip")
+        ctx.save_for_backward(xr, xt, xs, yr, yt, gp, ip, lp, ln)
+        ctx.extra = (c2p, nbr, visb, gamma, m, R, M)
+        return loss[:R]
+
+    @staticmethod
+    def backward(ctx, gout):
+        xr, xt, xs, yr, yt, gp, ip, lp, ln = ctx.saved_tensors
+        c2p, nbr, visb, gamma, m, R, M = ctx.extra
+        L = _lib.lib()
+        Rp, Mp = lp.shape[0], (M + 127) // 128 * 128
+        z = lp[:R] + ln[:R]
+        sig = torch.where(z > 20.0, torch.ones_like(z), torch.sigmoid(z))            # d softplus
+        coef = torch.where(torch.isfinite(lp[:R]), gout.contiguous().float() * sig, torch.zeros_like(z))   # empty positive set: 0
+        coef = _pad_rows(coef, Rp, 0.0)
+        P = int(L.gdm_circle_match_bwd_parts(R, M))
+        gx = torch.empty((Rp, 128), dtype=torch.float32, device=lp.device)
+        gyp = torch.empty((P, Mp, 128), dtype=torch.float32, device=lp.device)
+        check(L.gdm_circle_match_bwd_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M, gp.data_ptr(),
+                                         c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
+                                         nbr.data_ptr() if nbr is not None else None, visb.data_ptr() if visb is not None else None,
+                                         gamma, m, lp.data_ptr(), ln.data_ptr(), coef.data_ptr(), gx.data_ptr(), gyp.data_ptr(), _stream()),
+              "gdm_circle_match_bwd_hip")
+        return gx[:R], gyp.sum(dim=0)[:M], None, None, None, None, None, None, None
+
+
+def circle_match(x, y, g, item, nbr=None, visb=None, c2=None, gamma=16.0, m=0.2):
+    """Per-row circle loss of unit scene rows x f32[R,128] against unit vertex rows y f32[M,128] WITHOUT the [R, M+1] similarity
+    matrix (geoMatch.py:117-136 + :55-100 + loss.py:441-494, forward and backward).  g int[R]: ground-truth vertex (M = none),
+    item int[R]: batch item; positives from `nbr` (circle_nbr_table) & `visb` (circle_visbits), or -- symmetric objects -- the two
+    columns g / c2 of each row.  Returns f32[R]; differentiable w.r.t. x and y."""
+    g = _idx32(g, "g")
+    item = _idx32(item, "item")
+    if c2 is not None:
+        c2 = _idx32(c2, "c2")
+    elif nbr is None or visb is None:
+        raise ValueError("circle_match: pass nbr and visb (radius-test positives) or c2 (symmetric objects)")
+    return _CircleMatch.apply(x, y, g, c2, item, nbr, visb, float(gamma), float(m))
+
+
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 

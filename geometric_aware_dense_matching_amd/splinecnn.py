@@ -221,10 +221,42 @@ class SplineCNN_Mesh(nn.Module):
         self._csr = None
         self._pairs = None
 
+    def set_symmetry(self, sys_idx):
+        """Symmetric object: sys_idx int[M] = index of each vertex's counterpart under the object's symmetry (the reference's
+        `cal_sys_idx`, SplineCNN.py:163-169, registered as buffer `sys_idx` :161).  Switches the training matching loss to
+        matching_loss_sys (geoMatch.py:138-141)."""
+        idx = torch.as_tensor(sys_idx).long().reshape(-1)
+        if idx.shape[0] != self.xyz.shape[0]:
+            raise ValueError("sys_idx must have one entry per model vertex (%d), got %d" % (self.xyz.shape[0], idx.shape[0]))
+        if "sys_idx" in self._buffers:
+            self.sys_idx = idx.to(self.xyz.device)
+        else:
+            self.register_buffer("sys_idx", idx.to(self.xyz.device))
+        self.sys_corr_idx = self.sys_idx
+
+    def set_symmetry_transform(self, R, t_mm):
+        """sys_idx from a symmetry transform of the model frame (SplineCNN.py:163-169: `sym_transforms[1]` of
+        misc.get_symmetry_transformations, t in mm): for every vertex the nearest vertex of the transformed model, by the HIP kNN."""
+        if not self.xyz.is_cuda:
+            raise RuntimeError("set_symmetry_transform runs the HIP kNN: move the module to the GPU first")
+        Rm = torch.as_tensor(R, dtype=torch.float32, device=self.xyz.device).reshape(3, 3)
+        t = torch.as_tensor(t_mm, dtype=torch.float32, device=self.xyz.device).reshape(1, 3) / 1000.0
+        moved = (self.xyz @ Rm.t() + t).contiguous()
+        self.set_symmetry(ops.knn_batch(moved[None], self.xyz[None].contiguous(), 1)[0, :, 0])
+
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        if prefix + "mesh_graph_edge_index" in state_dict:
-            self.graph_ready = True                                       # graph comes with the checkpoint
+        ei = state_dict.get(prefix + "mesh_graph_edge_index")
+        if ei is not None and bool(torch.as_tensor(ei).any()):
+            self.graph_ready = True                                       # a real graph comes with the checkpoint
             self._csr = None
+        elif ei is not None:
+            # the all-zero placeholder of a state_dict taken before the first GPU forward: keep building the graph here
+            state_dict = dict(state_dict)
+            state_dict[prefix + "mesh_graph_edge_index"] = self.mesh_graph_edge_index
+            if prefix + "mesh_graph_edge_attr" in state_dict:
+                state_dict[prefix + "mesh_graph_edge_attr"] = self.mesh_graph_edge_attr
+        if prefix + "sys_idx" in state_dict and "sys_idx" not in self._buffers:
+            self.set_symmetry(state_dict[prefix + "sys_idx"])
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _ensure_graph(self):

@@ -220,6 +220,32 @@ int gdm_circle_rows_bwd_hip(const float* sim, int R, int Mp, const int32_t* matc
                             const float* lse_p, const float* lse_n, const float* grad_rows, float* dsim, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Training matching loss without the similarity matrix (gdm_circle.hip): replaces models/geoMatch.py:117-136 (normalise, padded
+ * matmul), :55-83 / :86-100 (positive masks) and models/loss.py:441-494 (CircleLoss) and their autograd backward for all selected
+ * points of a batch.  x f32[R,128] / y f32[M,128] are UNIT rows (F.normalize stays with the caller's autograd).
+ *   pack      x -> split-bf16 rows + d-major tiles + row sums (sizes from the two *_bytes functions, rows padded to 128)
+ *   nbr       bit table [M][ceil(M/32)] of vertices within `radius` of each vertex (basic_utils.py:86-89 arithmetic); once per model
+ *   visbits   visible_flag u8[B,M] -> bits [B][ceil(M/32)]
+ *   fwd       per-row lse_p, lse_n, loss f32[Rp]; g i32[Rp] = ground-truth vertex (M = none), item i32[Rp]; symmetric objects:
+ *             g / c2 = the two positive columns of the row (geoMatch.py:91-95), nbr / visb unused
+ *   bwd       coef f32[Rp] = upstream gradient x sigmoid(lse_p + lse_n) (0 for padding rows and empty positive sets) ->
+ *             gx f32[Rp,128], gy_part f32[P][Mp,128] with P = gdm_circle_match_bwd_parts (sum over P = gradient w.r.t. y)    */
+size_t gdm_circle_match_rows_bytes(int n);
+size_t gdm_circle_match_tp_bytes(int n);
+int gdm_circle_match_pack_hip(const float* x, int n, void* rows, void* tp, float* rowsum, void* stream);
+int gdm_circle_match_nbr_hip(const float* xyz, int M, float radius, uint32_t* nbr, void* stream);
+int gdm_circle_match_visbits_hip(const uint8_t* vis, int B, int M, uint32_t* bits, void* stream);
+int gdm_circle_match_fwd_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
+                             int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                             const uint32_t* nbr, const uint32_t* visb, float gamma, float m,
+                             float* lse_p, float* lse_n, float* loss, void* stream);
+int gdm_circle_match_bwd_parts(int R, int M);
+int gdm_circle_match_bwd_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
+                             int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                             const uint32_t* nbr, const uint32_t* visb, float gamma, float m,
+                             const float* lse_p, const float* lse_n, const float* coef, float* gx, float* gy_part, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * One attentive-pooling stage of RandLA-Net's local feature aggregation in a single launch (inference):
  * models/RandLA/RandLANet.py:700-718 Building_block.forward = two such stages; :720-727 relative_pos_encoding, :729-738
  * gather_neighbour, :747-754 Att_pooling.forward.  For every point i with neighbours idx[b,i,0..15]:
