@@ -35,6 +35,10 @@ SIGNATURES = {
     "gdm_knn_jobs_ws_hip": (_i, [ctypes.POINTER(KnnJob), _i, _i, _vp, _sz, _vp]),
     "gdm_ballquery_hip": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "gdm_furthestsampling_hip": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gdm_interpolation_forward_hip": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gdm_interpolation_backward_hip": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gdm_labelstat_ballrange_hip": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gdm_labelstat_idx_hip": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gdm_group_gather_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_group_gather_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_gather_max_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -183,7 +183,7 @@ class _GatherMax(torch.autograd.Function):
         B, C, n = feat.shape
         m, K = idx.shape[1], idx.shape[2]
         out = torch.empty((B, C, m), dtype=torch.float32, device=feat.device)
-        need_arg = feat.requires_grad
+        need_arg = ctx.needs_input_grad[0]               # (not feat.requires_grad: _dev may have made a contiguous copy under no_grad)
         arg = torch.empty((B, C, m), dtype=torch.int32, device=feat.device) if need_arg else None
         check(_lib.lib().gdm_gather_max_hip(feat.data_ptr(), idx.data_ptr(), B, C, n, m, K, out.data_ptr(),
                                             arg.data_ptr() if need_arg else None, _stream()), "gdm_gather_max_hip")

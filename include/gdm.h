@@ -80,6 +80,20 @@ int gdm_ballquery_hip(int B, int n, int m, float radius, int nsample,
  * starts from index 0, `temp` f32[B,n] is scratch (initialised inside).                  */
 int gdm_furthestsampling_hip(int B, int n, int m, const float* xyz, float* temp, int32_t* idx, void* stream);
 
+/* Three-point interpolation (pointops.py:114-144 `interpolation_forward/backward_cuda`): feat f32[b,c,m], idx i32[b,n,3],
+ * weight f32[b,n,3] -> out f32[b,c,n]; backward scatters grad_out f32[b,c,n] into a ZERO-FILLED grad_feat f32[b,c,m].  */
+int gdm_interpolation_forward_hip(int B, int c, int m, int n, const float* feat, const int32_t* idx, const float* weight, float* out, void* stream);
+int gdm_interpolation_backward_hip(int B, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
+                                   float* grad_feat, void* stream);
+
+/* Label histograms (pointops.py:289-338): label_stat i32[b,n,nclass] summed over the points inside the ball of each centre
+ * (`labelstat_ballrange_cuda(b,n,m,radius,nclass,new_xyz,xyz,label_stat,new_label_stat)`) or over idx i32[b,m,nsample]
+ * (`labelstat_idx_cuda(b,n,m,nsample,nclass,label_stat,idx,new_label_stat)`) -> i32[b,m,nclass].                        */
+int gdm_labelstat_ballrange_hip(int B, int n, int m, float radius, int nclass, const float* new_xyz, const float* xyz,
+                                const int32_t* label_stat, int32_t* new_label_stat, void* stream);
+int gdm_labelstat_idx_hip(int B, int n, int m, int nsample, int nclass, const int32_t* label_stat, const int32_t* idx,
+                          int32_t* new_label_stat, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Feature gather / scatter (channel-major features, as the reference network keeps them).
  * ------------------------------------------------------------------------------------- */
