@@ -361,8 +361,16 @@ def main():
 
     graph = None
     with torch.no_grad():
+        # warm-up = MIOpen find mode for the few convolutions that stay on MIOpen (stem, layer1/2) + the per-module caches.  With
+        # several ranks on one node, rank 0 goes first and fills MIOpen's user database; the others then start from it instead of
+        # all N benchmarking the same shapes (and locking the same file) at once
+        if world > 1 and rank != 0:
+            dist.barrier()
         for _ in range(args.warmup):
             step()
+        torch.cuda.synchronize()
+        if world > 1 and rank == 0:
+            dist.barrier()
         sync_all()
         if not args.eager:
             # one capture of the whole step on the resident inputs (after the eager warm-up above: MIOpen has picked its kernels,
@@ -385,6 +393,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        dt_enqueue = time.perf_counter() - t1                      # host time to issue the eager steps (no wait for the GPU)
         sync_all()
         dt_eager = time.perf_counter() - t1
         # stage breakdown from a few more, instrumented, eager steps OUTSIDE the timed region: five event records per step cost
@@ -469,7 +478,10 @@ def main():
 
     extras, rooflines = None, None
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "eager_crops_per_s": round(B * args.steps / dt_eager, 1)}
+        extras = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "eager_crops_per_s": round(B * args.steps / dt_eager, 1),
+                  "eager_host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3),
+                  "note": "eager = one host call per kernel (~240 per step): a rank then needs a host core of its own; the headline's "
+                          "graph replay needs one call per step"}
         extras.update(extra_legs(torch, dev, args, model, N, M))
         rooflines = [dict(roofline, name="match materialised"), dict(roofline_fused, name="match fused")] + kernel_rooflines(torch, dev, B, N)
 

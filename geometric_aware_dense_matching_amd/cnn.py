@@ -74,18 +74,30 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if fused_eval(x, self) and self._mfma_ok(x):
-            # layer3 / layer4 at 32x32: both 3x3 convolutions on the split-bf16 MFMA implicit-GEMM kernel with BN, ReLU and
-            # the residual add in its epilogue (MIOpen's fp32 path here is a vector-ALU Winograd kernel, 2.7x slower)
+            # 64 x 64 and 32 x 32 stages: both 3x3 convolutions on the split-bf16 MFMA implicit-GEMM kernel with BN, ReLU and the
+            # residual add in its epilogue (MIOpen's fp32 path here is a vector-ALU Winograd kernel, 2.7x slower).  The epilogue
+            # also writes the NEXT convolution's operand (bf16 hi / lo planes): conv1 -> conv2 needs no fp32 map at all, and a block
+            # hands its packed output to the next block on the tensor it returns (`_gdm_packed`), so one pack launch feeds a whole
+            # chain of blocks.
             s1, b1 = folded_bn(self.bn1)
             planes = self.conv1.weight.shape[0]
-            out = ops.conv3x3_bf16x3(x, self._packed_weight(self.conv1), planes, s1, b1, ops.ACT_RELU)
+            xin = getattr(x, "_gdm_packed", None)
+            if xin is None or xin.shape != tuple(x.shape):
+                xin = x
+            chain = (x.shape[0] * x.shape[2] * x.shape[3]) % 256 == 0
+            mid = ops.conv3x3_bf16x3(xin, self._packed_weight(self.conv1), planes, s1, b1, ops.ACT_RELU, out_f32=not chain, out_packed=chain)
+            mid = mid[1] if chain else mid
             s2, b2 = folded_bn(self.bn2)
             if self.downsample is None:
                 res = x
             else:
                 sd, bd = folded_bn(self.downsample[1])
                 res = ops.affine_act(self.downsample[0](x), sd, bd, ops.ACT_NONE)
-            return ops.conv3x3_bf16x3(out, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res)
+            if not chain:
+                return ops.conv3x3_bf16x3(mid, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res)
+            out, opk = ops.conv3x3_bf16x3(mid, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res, out_packed=True)
+            out._gdm_packed = opk
+            return out
         if fused_eval(x, self):
             # eval: conv -> [BN+ReLU] -> conv -> [BN + (BN'd) residual + ReLU], each bracket one HIP launch
             s1, b1 = folded_bn(self.bn1)

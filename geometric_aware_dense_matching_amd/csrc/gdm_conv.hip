@@ -123,7 +123,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
                                                                     // pixel rowidx[r] and every 256-row tile has its own 128 output channels
                                                                     // [tile_co0[tile], +128) of the packed weights; the tile is stored 128 wide
                                                                     const int32_t* __restrict__ rowidx = nullptr,
-                                                                    const int32_t* __restrict__ tile_co0 = nullptr)
+                                                                    const int32_t* __restrict__ tile_co0 = nullptr,
+                                                                    // NCHW form only: the result ALSO (or only, out == nullptr) as the
+                                                                    // next convolution's packed operand (planes of [B, Cout] at H x W)
+                                                                    unsigned char* __restrict__ outpk = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,20 +281,27 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
         }
         return;
     }
+    // Packed output: the tile goes through LDS (the weight panels are dead) to turn "lane = channel, registers = pixels" into
+    // "lane = pixel, 8 consecutive channels = one 16-byte fragment", is split to bf16 hi / lo there and stored into the planes of
+    // the next layer's operand: 32 consecutive pixels x 16 B = 512-B runs.  Saves that layer's pack kernel and, when the fp32 map
+    // has no other reader, the fp32 store.
+    constexpr int TSTRIDE = 132;                                     // floats per pixel row of the wave's tile (128 + 4: conflict-free reads)
+    float* tl = reinterpret_cast<float*>(smem) + wave * 32 * TSTRIDE;
+    if (outpk) __syncthreads();                                      // every wave has finished reading the last weight panel
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int co = co0 + cb * 32 + lr;
-        if (co >= Cout) continue;
-        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-        float* op = out + ((long)b * Cout + co) * hw + prem;
-        const float* rp = HAS_RES ? res + ((long)b * Cout + co) * hw + prem : nullptr;
+        const bool live = co < Cout;
+        const float sc = (live && scale) ? scale[co] : 1.f, sh = (live && shift) ? shift[co] : 0.f;
+        float* op = out ? out + ((long)b * Cout + (live ? co : 0)) * hw + prem : nullptr;
+        const float* rp = (HAS_RES && live) ? res + ((long)b * Cout + co) * hw + prem : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int poff = 8 * g + 4 * h;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[cb][4 * g + j] * sc + sh;
-            if (HAS_RES) {
+            if (HAS_RES && live) {
                 const float4 r4 = *reinterpret_cast<const float4*>(rp + poff);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
@@ -299,7 +309,29 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
+            if (op && live) *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
+            if (outpk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tl[(poff + j) * TSTRIDE + cb * 32 + lr] = live ? v[j] : 0.f;
+            }
+        }
+    }
+    if (outpk) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int ochunks = (Cout + 127) / 128;
+        const int ochunk = co0 / 128;
+        unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * plane + (long)(y + 1) * (W + 2) + x0 + lr + 1) * 16;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = 2 * it + h;                                // 8-channel group of this workgroup's 128 channels
+            if (co0 + q * 8 >= Cout) continue;
+            const float4 a0 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8 + 4);
+            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            unsigned hi[4], lo[4];
+            split8(v, hi, lo);
+            *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
     }
 }
@@ -316,8 +348,8 @@ extern "C" size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W)
 
 extern "C" size_t gdm_conv3x3_weight_bytes(int Cout, int Cin)
 {
-    if (Cout < 1 || Cin < 128 || Cin % 128) return 0;
-    return (size_t)9 * (Cin / 128) * ((Cout + 127) & ~127) * ROWB;
+    if (Cout < 1 || !cin_ok(Cin)) return 0;
+    return (size_t)9 * ((Cin + 127) / 128) * ((Cout + 127) & ~127) * ROWB;
 }
 
 extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
@@ -329,7 +361,7 @@ extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
 static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who)
 {
     GDM_CHECK_ARG(w && wpk, "%s: NULL pointer", who);
-    GDM_CHECK_ARG(Cout >= 1 && cin_ok(Cin) && (taps == 1 || Cin % 128 == 0), "%s: Cout=%d Cin=%d (a multiple of 128; 64 for the 1x1 form)", who, Cout, Cin);
+    GDM_CHECK_ARG(Cout >= 1 && cin_ok(Cin), "%s: Cout=%d Cin=%d (Cin a multiple of 128, or 64)", who, Cout, Cin);
     const long items = (long)taps * ((Cin + 127) / 128) * ((Cout + 127) & ~127) * 16;
     hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk);
     return gdm_launch_status("conv_pack_w_kernel");
@@ -355,29 +387,49 @@ extern "C" int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, i
     return gdm_launch_status("conv_pack_act_kernel");
 }
 
+// out (fp32 NCHW) and / or outpk (the packed operand of the next convolution over [B, Cout, H, W]; zero-filled once by the caller, only
+// interior pixels are written) -- at least one of them.
+extern "C" int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                                       int B, int Cin, int Cout, int H, int W, int act, float* out, void* outpk, void* stream)
+{
+    GDM_CHECK_ARG(xpk && wpk && (out || outpk), "gdm_conv3x3_packed_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && ((long)B * H * W) % 32 == 0, "gdm_conv3x3_packed_hip: W=%d must be a multiple of 32", W);
+    GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv3x3_packed_hip: act=%d", act);
+    GDM_CHECK_ARG(!outpk || (Cout % 8 == 0 && ((long)B * H * W) % CV_PIX == 0),
+                  "gdm_conv3x3_packed_hip: packed output needs Cout %% 8 == 0 and B*H*W %% 256 == 0 (got Cout=%d, B*H*W=%ld)", Cout, (long)B * H * W);
+    const long ptot = (long)B * H * W;
+    dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int SMEM = 2 * CV_PANEL > 8 * 32 * 132 * 4 ? 2 * CV_PANEL : 8 * 32 * 132 * 4;      // panels, or the eight waves' output tiles
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, true, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, true, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr = true;
+    }
+#define CV(A, R, NK) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, R, 9, false, NK>), grid, dim3(CV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
+    if (Cin == 64) {                                             // one half-filled chunk: only its four non-zero k-steps are run
+        if (act == 0) { if (res) CV(0, true, 4); else CV(0, false, 4); }
+        else { if (res) CV(1, true, 4); else CV(1, false, 4); }
+    } else {
+        if (act == 0) { if (res) CV(0, true, 8); else CV(0, false, 8); }
+        else { if (res) CV(1, true, 8); else CV(1, false, 8); }
+    }
+#undef CV
+    return gdm_launch_status("conv3x3_bf16x3_kernel");
+}
+
 extern "C" int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                                       int B, int Cin, int Cout, int H, int W, int act, float* out, void* stream)
 {
-    GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv3x3_packed_hip: NULL pointer");
-    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (multiples of 128)", Cin, Cout);
-    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && ((long)B * H * W) % 32 == 0, "gdm_conv3x3_packed_hip: W=%d must be a multiple of 32", W);
-    GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv3x3_packed_hip: act=%d", act);
-    const long ptot = (long)B * H * W;
-    dim3 grid(gdm_cdiv(ptot, CV_PIX), Cout / CV_CO);
-    hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
-        attr = true;
-    }
-#define CV(A, R) hipLaunchKernelGGL((conv3x3_bf16x3_kernel<A, R>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out)
-    if (act == 0) { if (res) CV(0, true); else CV(0, false); }
-    else { if (res) CV(1, true); else CV(1, false); }
-#undef CV
-    return gdm_launch_status("conv3x3_bf16x3_kernel");
+    return gdm_conv3x3_packed2_hip(xpk, wpk, scale, shift, res, B, Cin, Cout, H, W, act, out, nullptr, stream);
 }
 
 // Grouped, gathered GEMM on the same kernel: Y[r, 0:128] = Wpk[tile_co0[r / 256] + 0:128, :] . X[rowidx[r], :] for R rows (R % 256 == 0),

@@ -838,9 +838,10 @@ _conv_act_cache = {}
 
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1)):
+    cin = weight.shape[1]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
             and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1)
-            and weight.shape[1] % 128 == 0 and weight.shape[0] % 128 == 0 and x.shape[3] % 32 == 0 and x.shape[0] <= 65535)
+            and (cin == 64 or cin % 128 == 0) and weight.shape[0] % 8 == 0 and x.shape[3] % 32 == 0 and x.shape[0] <= 65535)
 
 
 def conv3x3_pack_weight(weight):
@@ -853,26 +854,59 @@ def conv3x3_pack_weight(weight):
     return wpk
 
 
-def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None):
-    """3x3/s1/p1 convolution of x f32[B,Cin,H,W] with packed weights on split-bf16 MFMA (+ per-channel scale/shift,
-    optional residual, optional ReLU).  Inference only."""
+class PackedAct:
+    """An activation map in the convolution kernel's operand layout (bf16 hi / lo planes of 8 channels, one-pixel zero border):
+    what conv3x3_bf16x3(..., out_packed=True) hands to the next convolution instead of a pack launch."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+
+def _packed_buffer(B, C, H, W, device, avoid=None):
+    """Zero-bordered operand buffer for [B,C,H,W] from a small per-shape pool (two per shape and stream: a layer reads one and
+    writes the other).  Only interior pixels are ever written, so the border stays zero."""
+    key = (B, C, H, W, device.index, torch.cuda.current_stream().cuda_stream)
+    pool = _conv_act_cache.setdefault(key, [])
+    for buf in pool:
+        if avoid is None or buf.data_ptr() != avoid.data_ptr():
+            return buf
+    buf = torch.zeros(_lib.lib().gdm_conv3x3_act_bytes(B, C, H, W), dtype=torch.uint8, device=device)
+    pool.append(buf)
+    return buf
+
+
+def conv3x3_pack_act(x):
+    """x f32[B,C,H,W] -> PackedAct (one launch)."""
     x = _dev(x, torch.float32, "x")
-    B, Cin, H, W = x.shape
+    B, C, H, W = x.shape
+    buf = _packed_buffer(B, C, H, W, x.device)
+    check(_lib.lib().gdm_conv3x3_pack_act_hip(x.data_ptr(), B, C, H, W, buf.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
+    return PackedAct(buf, (B, C, H, W))
+
+
+def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None, out_f32=True, out_packed=False):
+    """3x3/s1/p1 convolution of x f32[B,Cin,H,W] (or a PackedAct) with packed weights on split-bf16 MFMA (+ per-channel scale/shift,
+    optional residual, optional ReLU).  Returns the fp32 map, or -- out_packed -- (fp32 map or None, PackedAct of the result): the
+    epilogue writes the next convolution's operand itself.  Inference only."""
+    xp = x if isinstance(x, PackedAct) else conv3x3_pack_act(x)
+    B, Cin, H, W = xp.shape
     L = _lib.lib()
-    key = (B, Cin, H, W, x.device.index, torch.cuda.current_stream().cuda_stream)
-    xpk = _conv_act_cache.get(key)
-    if xpk is None:
-        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(B, Cin, H, W), dtype=torch.uint8, device=x.device)   # zero border, kept
-        _conv_act_cache[key] = xpk
-    check(L.gdm_conv3x3_pack_act_hip(x.data_ptr(), B, Cin, H, W, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    dev = xp.buf.device
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev) if out_f32 else None
+    opk = None
+    if out_packed:
+        if (B * H * W) % 256 != 0 or cout % 8 != 0:
+            raise ValueError("conv3x3_bf16x3: packed output needs B*H*W %% 256 == 0 and Cout %% 8 == 0")
+        opk = PackedAct(_packed_buffer(B, cout, H, W, dev, avoid=xp.buf), (B, cout, H, W))
     if res is not None:
         res = _dev(res, torch.float32, "res")
-        assert res.shape == out.shape
-    check(L.gdm_conv3x3_packed_hip(xpk.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                   shift.data_ptr() if shift is not None else None, res.data_ptr() if res is not None else None,
-                                   B, Cin, cout, H, W, act, out.data_ptr(), _stream()), "gdm_conv3x3_packed_hip")
-    return out
+        assert tuple(res.shape) == (B, cout, H, W)
+    check(L.gdm_conv3x3_packed2_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                    shift.data_ptr() if shift is not None else None, res.data_ptr() if res is not None else None,
+                                    B, Cin, cout, H, W, act, out.data_ptr() if out is not None else None,
+                                    opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_conv3x3_packed2_hip")
+    return (out, opk) if out_packed else out
 
 
 class _Conv3x3Train(torch.autograd.Function):
@@ -923,11 +957,7 @@ def gemm_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, pixel_major=
     x = _dev(x, torch.float32, "x")
     B, Cin, n = x.shape
     L = _lib.lib()
-    key = (B, Cin, 1, n, x.device.index, torch.cuda.current_stream().cuda_stream)
-    xpk = _conv_act_cache.get(key)
-    if xpk is None:
-        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(B, Cin, 1, n), dtype=torch.uint8, device=x.device)
-        _conv_act_cache[key] = xpk
+    xpk = _packed_buffer(B, Cin, 1, n, x.device)
     check(L.gdm_conv3x3_pack_act_hip(x.data_ptr(), B, Cin, 1, n, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
     out = torch.empty((B * n, cout) if pixel_major else (B, cout, n), dtype=torch.float32, device=x.device)
     check(L.gdm_conv1x1_packed_hip(xpk.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
@@ -943,11 +973,7 @@ def gemm_grouped(x_cm, wpk, rowidx, tile_co0, cout_total):
     _, Cin, M = x_cm.shape
     R = rowidx.shape[0]
     L = _lib.lib()
-    key = (1, Cin, 1, M, x_cm.device.index, torch.cuda.current_stream().cuda_stream)
-    xpk = _conv_act_cache.get(key)
-    if xpk is None:
-        xpk = torch.zeros(L.gdm_conv3x3_act_bytes(1, Cin, 1, M), dtype=torch.uint8, device=x_cm.device)
-        _conv_act_cache[key] = xpk
+    xpk = _packed_buffer(1, Cin, 1, M, x_cm.device)
     check(L.gdm_conv3x3_pack_act_hip(x_cm.data_ptr(), 1, Cin, 1, M, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
     Y = torch.empty((R, 128), dtype=torch.float32, device=x_cm.device)
     check(L.gdm_gemm_grouped_hip(xpk.data_ptr(), wpk.data_ptr(), rowidx.data_ptr(), tile_co0.data_ptr(), R, M, Cin, cout_total,

@@ -351,6 +351,10 @@ int gdm_conv3x3_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, vo
 int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, int W, void* xpk, void* stream);
 int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                            int B, int Cin, int Cout, int H, int W, int act, float* out, void* stream);
+/* The same convolution with the result ALSO (or only: out == NULL) written as the packed operand of the next convolution
+ * (outpk: gdm_conv3x3_act_bytes(B, Cout, H, W) bytes, zero-filled once by the caller), which then needs no pack launch.  */
+int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                            int B, int Cin, int Cout, int H, int W, int act, float* out, void* outpk, void* stream);
 
 /* `final` stage of the image branch (pspnet.py:108-112): out = log_softmax_c(W x + b), x,out f32[B,64,hw], W f32[64,64]. */
 int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream);

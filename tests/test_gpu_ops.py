@@ -362,6 +362,45 @@ def test_conv3x3_bf16x3_vs_fp32_conv(ops, B, Cin, Cout, H, W):
     assert torch.equal(got, got3)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 64, 64), (1, 64, 128, 8, 32), (2, 128, 64, 4, 32), (1, 256, 200, 8, 32)])
+def test_conv3x3_bf16x3_small_channel_counts(ops, B, Cin, Cout, H, W):
+    """Cin = 64 (one half-filled 128-channel chunk: the 64 x 64 stage of the trunk) and output channel counts that are not multiples
+    of 128 (zero weight rows, masked stores), against the fp64 convolution."""
+    rs = np.random.RandomState(Cin * 3 + Cout)
+    x = torch.from_numpy(rs.randn(B, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(np.float32))
+    assert ops.conv3x3_supported(x.cuda(), w.cuda())
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    got = ops.conv3x3_bf16x3(x.cuda(), ops.conv3x3_pack_weight(w.cuda()), Cout).cpu()
+    assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C1,C2,C3,H,W", [(2, 128, 256, 256, 32, 32), (1, 64, 64, 64, 64, 64), (1, 128, 64, 72, 8, 32), (2, 256, 128, 200, 4, 32)])
+def test_conv3x3_packed_output_feeds_the_next_convolution(ops, B, C1, C2, C3, H, W):
+    """The epilogue's packed output (bf16 hi / lo planes written straight from the accumulators) == packing the fp32 result with
+    the pack kernel, bit for bit, so conv -> conv through it equals conv -> pack -> conv exactly; with and without the fp32 map."""
+    rs = np.random.RandomState(C1 + C2 + C3)
+    x = torch.from_numpy(rs.randn(B, C1, H, W).astype(np.float32)).cuda()
+    w1 = torch.from_numpy((rs.randn(C2, C1, 3, 3) / np.sqrt(C1 * 9)).astype(np.float32)).cuda()
+    w2 = torch.from_numpy((rs.randn(C3, C2, 3, 3) / np.sqrt(C2 * 9)).astype(np.float32)).cuda()
+    sc = torch.from_numpy((1 + 0.1 * rs.randn(C2)).astype(np.float32)).cuda()
+    sh = torch.from_numpy((0.1 * rs.randn(C2)).astype(np.float32)).cuda()
+    res = torch.from_numpy(rs.randn(B, C2, H, W).astype(np.float32)).cuda()
+    p1, p2 = ops.conv3x3_pack_weight(w1), ops.conv3x3_pack_weight(w2)
+    mid = ops.conv3x3_bf16x3(x, p1, C2, sc, sh, ops.ACT_RELU, res)
+    want = ops.conv3x3_bf16x3(mid, p2, C3)
+    mid_f32, mid_pk = ops.conv3x3_bf16x3(x, p1, C2, sc, sh, ops.ACT_RELU, res, out_packed=True)
+    assert torch.equal(mid_f32, mid) and isinstance(mid_pk, ops.PackedAct) and mid_pk.shape == (B, C2, H, W)
+    got = ops.conv3x3_bf16x3(mid_pk, p2, C3)
+    assert torch.equal(got, want)
+    none_f32, only_pk = ops.conv3x3_bf16x3(x, p1, C2, sc, sh, ops.ACT_RELU, res, out_f32=False, out_packed=True)
+    assert none_f32 is None and torch.equal(ops.conv3x3_bf16x3(only_pk, p2, C3), want)
+    # the pooled operand buffers keep their zero border over repeated use
+    for _ in range(3):
+        _, pk = ops.conv3x3_bf16x3(x, p1, C2, sc, sh, ops.ACT_RELU, res, out_f32=False, out_packed=True)
+        assert torch.equal(ops.conv3x3_bf16x3(pk, p2, C3), want)
+
+
 def test_final_stage_and_psp_pools(ops):
     rs = np.random.RandomState(12)
     x = torch.from_numpy(rs.randn(2, 64, 40, 24).astype(np.float32))
