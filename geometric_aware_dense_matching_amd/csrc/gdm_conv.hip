@@ -205,32 +205,35 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
         const unsigned char* base = smem + ((GDM_CONV_EXP & 1) ? 0 : (it & 1)) * CV_PANEL;
         // 16 units of (k-step s, output-block pair p): 6 MFMAs on this unit's fragments while the next unit's four fragment
         // reads are in flight
-        u32x4 fh[2], fl[2];
+        // fragments of unit u live in ring slot u % (PF + 1); PF units' reads are in flight while a unit's MFMAs issue
+#ifndef GDM_CONV_PF
+#define GDM_CONV_PF 2
+#endif
+        constexpr int PF = GDM_CONV_PF;
+        constexpr int NU = 2 * NKS;
+        u32x4 fh[PF + 1][2], fl[PF + 1][2];
+        auto frag_load = [&](int un) {
+            const int sn = un >> 1, pn = un & 1, slot = un % (PF + 1);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fh[j] = *reinterpret_cast<const u32x4*>(base + swz(j * 32 + lr, h));
-            fl[j] = *reinterpret_cast<const u32x4*>(base + swz(j * 32 + lr, 16 + h));
-        }
-#pragma unroll
-        for (int u = 0; u < 2 * NKS; ++u) {
-            const int s = u >> 1, pr = u & 1;
-            u32x4 nh[2], nl[2];
-            if (u < 2 * NKS - 1) {
-                const int sn = (u + 1) >> 1, pn = (u + 1) & 1;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    nh[j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 2 * sn + h));
-                    nl[j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 16 + 2 * sn + h));
-                }
+            for (int j = 0; j < 2; ++j) {
+                fh[slot][j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 2 * sn + h));
+                fl[slot][j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 16 + 2 * sn + h));
             }
+        };
+#pragma unroll
+        for (int un = 0; un < PF; ++un) frag_load(un);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int s = u >> 1, pr = u & 1, slot = u % (PF + 1);
+            if (u + PF < NU) frag_load(u + PF);
             const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[s]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, alo[s]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fl[j]), acc[2 * pr + j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fl[slot][j]), acc[2 * pr + j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[slot][j]), acc[2 * pr + j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[j]), acc[2 * pr + j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[slot][j]), acc[2 * pr + j], 0, 0, 0);
             if (pr == 1 && s < NKS - LATE && !(GDM_CONV_EXP & 2)) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
             if (u == 0) {
                 // issued BEHIND the first MFMAs: the wait hipcc puts in front of them for the loop-carried operand registers
@@ -241,19 +244,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
                     for (int ss = NKS - LATE; ss < NKS; ++ss) load_a(rcur, ss);
                 }
             }
-            if (u < 2 * NKS - 1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    fh[j] = nh[j];
-                    fl[j] = nl[j];
-                }
-            }
             // one scheduling region per unit (the scheduler otherwise regroups the MFMAs accumulator-major, which pulls the
             // late operand loads to the front); inside it: MFMA : ds_read 1:1, the operand reloads behind the MFMAs
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u < 2 * NKS - 1 && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (u + PF < NU && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

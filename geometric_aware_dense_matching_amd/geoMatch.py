@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops, settings
 from .ffb6d import FFB6DEmb
 from .layers import PtSeq, pt_conv1d
 from .loss import AutomaticWeightedLoss, CircleLoss, FocalLoss
@@ -125,8 +126,16 @@ class GeoMatch(nn.Module):
     def forward(self, inputs, end_points=None):
         if not end_points:
             end_points = {}
-        rgbd_emb = self.pcd_emb(inputs)
-        mesh_features = self.mesh_features()
+        rgb = inputs["rgb"]
+        if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
+            # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
+            with ops.fork(rgb.device, 1) as f:
+                mesh_features = self.mesh_features()
+            rgbd_emb = self.pcd_emb(inputs)
+            f.join(mesh_features)
+        else:
+            rgbd_emb = self.pcd_emb(inputs)
+            mesh_features = self.mesh_features()
         rgbd_features = self.feature_encoding_layer(rgbd_emb)
         rgbd_normalized = self.normalize_feature_layer(rgbd_features)
         rgbd_emb = rgbd_emb + rgbd_normalized

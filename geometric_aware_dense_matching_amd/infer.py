@@ -66,7 +66,7 @@ class GraphedPipeline:
     def _step(self):
         d = dict(self.static_in)
         if "cld_nei_idx0" not in d:
-            d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"]))
+            d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"], overlap=True))
         ep = self.model(d)
         res = matching.match_frames(ep, precision=self.precision)
         out = dict(seg=ep["seg"], rgbd=ep["rgbd"], mesh=ep["mesh"], mask=res["mask"], count=res["count"],

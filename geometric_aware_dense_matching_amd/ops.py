@@ -29,6 +29,49 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_side_streams = {}
+
+
+def side_stream(device, which=0):
+    """A per-device side stream (HIP streams let independent branches of the step overlap: most of its ~230 kernels are far too
+    small to fill 256 CUs).  Callers fork with side.wait_stream(current), join with current.wait_stream(side)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+class fork:
+    """with ops.fork(device, which) as side: ...   -- the body is enqueued on a side stream that starts after everything already on
+    the current stream; `join()` afterwards makes the current stream wait for it.  Works eagerly and inside hipGraph capture."""
+
+    def __init__(self, device, which=0, after=None):
+        self.side = side_stream(device, which)
+        self.cur = torch.cuda.current_stream(device)
+        self.after = after
+        self._ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.cur)
+        if self.after is not None and self.after[1] is not self.side:      # (event, stream it was recorded on): same stream = ordered
+            self.side.wait_event(self.after[0])
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        """Tensors made on the side stream may be used on the current stream from here on.  No record_stream is needed: a side
+        stream only ever runs inside fork(), which begins by waiting for the current stream, so by the time a freed block can be
+        handed out again on the side stream every consumer already enqueued on the current stream is ordered before it."""
+        self.cur.wait_stream(self.side)
+
+
 def _dev(t, dtype, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("%s must be a CUDA (HIP) tensor: the geoMatch ops have no CPU fallback" % name)

@@ -26,9 +26,23 @@ def cloud_from_inputs(cld_rgb_nrm):
     return cld_rgb_nrm[:, :3, :].transpose(1, 2).contiguous()
 
 
-def build_pyramid(cld, dpt_xyz):
+READY = "_pyramid_ready"          # key of the event recorded behind an overlapped pyramid build
+
+
+def build_pyramid(cld, dpt_xyz, overlap=False):
+    """overlap=True (inference): the searches are enqueued on a side stream, so that the image trunk's first stages -- which
+    need no indices -- run beside them; the returned dict then carries the event every consumer must wait for under READY
+    (FFB6DEmb.forward does; `wait_ready(pyr)` for other consumers)."""
     if not (cld.is_cuda and dpt_xyz.is_cuda):
         raise RuntimeError("build_pyramid runs on the GPU (HIP kNN); there is no CPU fallback")
+    from . import settings
+    if overlap and settings.USE_SIDE_STREAMS and "pyr" in settings.SIDE_PARTS:
+        with ops.fork(cld.device, 0) as f:
+            pyr = build_pyramid(cld, dpt_xyz)
+            ev = torch.cuda.Event()
+            ev.record(f.side)
+        pyr[READY] = (ev, f.side)
+        return pyr
     B, N, _ = cld.shape
     S = dpt_xyz.shape[1]
     assert dpt_xyz.shape == (B, S, S, 3)
@@ -59,3 +73,10 @@ def build_pyramid(cld, dpt_xyz):
         pyr["cld_xyz%d" % i] = levels[i]
         pyr["cld_sub_idx%d" % i] = pyr["cld_nei_idx%d" % i][:, : levels[i + 1].shape[1]]
     return pyr
+
+
+def wait_ready(inputs, stream=None):
+    """Make `stream` (default: the current one) wait for an overlapped pyramid build, if the inputs carry one."""
+    ev = inputs.get(READY)
+    if ev is not None:
+        (stream or torch.cuda.current_stream()).wait_event(ev[0])

@@ -15,6 +15,8 @@ the initial values.
     USE_FUSED_BN_TRAIN         GDM_FUSED_BN_TRAIN         training BatchNorm + activation on the torch modules
     USE_FUSED_SYNCBN           GDM_FUSED_SYNCBN           nn.SyncBatchNorm on torch's implementation
     USE_FUSED_MATCH_LOSS       GDM_FUSED_MATCH_LOSS       training similarity materialised by hipBLASLt, rows kernel for the circle loss
+    USE_SIDE_STREAMS           GDM_SIDE_STREAMS           everything on the caller's stream (inference otherwise forks the mesh branch, the
+                                                          neighbour pyramid and the point branch of each encoder stage onto side streams)
     UPCONV_MIN_CIN             GDM_UPCONV_MIN_CIN         (int) smallest Cin for the low-resolution form of conv3x3(upsample(x))
 """
 import os
@@ -35,8 +37,10 @@ USE_GROUPED_SPLINE = _flag("GDM_GROUPED_SPLINE")
 USE_FUSED_BN_TRAIN = _flag("GDM_FUSED_BN_TRAIN")
 USE_FUSED_SYNCBN = _flag("GDM_FUSED_SYNCBN")
 USE_FUSED_MATCH_LOSS = _flag("GDM_FUSED_MATCH_LOSS")
+USE_SIDE_STREAMS = _flag("GDM_SIDE_STREAMS")
+SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
-                "USE_FUSED_MATCH_LOSS")
+                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS")
