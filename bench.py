@@ -144,7 +144,7 @@ def kernel_rooflines(torch, dev, B, N):
         conv()
     ms = timed(conv, n, torch)
     fl = 2.0 * 9 * Cin * Cout * B * H * W
-    out.append({"kernel": "conv3x3_bf16x3_kernel 512->512 @32x32 (trunk layer4)", "bound": "mfma", "unit": "TFLOP/s",
+    out.append({"kernel": "conv_mfma16_kernel 3x3 512->512 @32x32 (trunk layer4)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4), "traffic": None,
                 "work": "2*9*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * H * W)})
@@ -248,7 +248,7 @@ def extra_legs(torch, dev, args, model, N, M):
         torch.cuda.synchronize()
         ms = timed(dg_step, 5, torch)
     out["dgcnn"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager", "batch": args.batch,
-                    "config": "geoMatch_DGCNN (k=16 cloud, k=20 mesh), N=%d x M=%d, fwd + matching" % (N, M)}
+                    "config": "geoMatch_DGCNN (k=16 for both trunks, as its cfg gives), N=%d x M=%d, fwd + matching" % (N, M)}
     del dg
 
     # ---- one training step (fwd + fused matching loss + bwd + Adam) at the reference's default training shape
