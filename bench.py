@@ -164,10 +164,10 @@ def kernel_rooflines(torch, dev, B, N):
         pairs += 2 * hw * lv[3 - i]
     pairs *= B
     valu_peak = 256 * 4 * 32 * 2.4e9 / 9.0 / 1e12        # 9 vector ops per pair (3 sub, 3 mul, 2 add, 1 compare)
-    out.append({"kernel": "knn_wave_kernel + knn_kernel<1> + knn_pack_kernel (whole neighbour pyramid, 22 searches per crop)", "bound": "valu",
+    out.append({"kernel": "knn_wave_kernel + knn_grid_kernel + knn_kernel<1> (+ pack / range kernels): whole neighbour pyramid, 22 searches per crop", "bound": "valu",
                 "unit": "Tpair/s", "achieved": round(pairs / ms / 1e9, 3), "peak": round(valu_peak, 2),
                 "frac": round(pairs / ms / 1e9 / valu_peak, 4), "avg_ms": round(ms, 4), "traffic": None,
-                "work": "%d brute-force pair distances per batch of %d crops; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 9 vector ops per pair" % (pairs, B)})
+                "work": "%d brute-force-equivalent pair distances per batch of %d crops (the searches against pixel grids visit a window, not all pairs); peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 9 vector ops per pair" % (pairs, B)})
     # (3) gather + max over K (random_sample, ffb6d.py:128-146): the largest call of the step, pixel -> point at 128 x 128
     C, n_src, m, K = 64, 128 * 128, N // 4, 16
     feat = torch.randn(B, C, n_src, device=dev)

@@ -21,7 +21,7 @@ class KnnJob(ctypes.Structure):
     """struct gdm_knn_job (include/gdm.h)."""
     _fields_ = [("support", _vp), ("query", _vp), ("idx", _vp), ("d2", _vp),
                 ("support_bstride", ctypes.c_int64), ("query_bstride", ctypes.c_int64),
-                ("S", ctypes.c_int32), ("Q", ctypes.c_int32), ("K", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+                ("S", ctypes.c_int32), ("Q", ctypes.c_int32), ("K", ctypes.c_int32), ("grid_w", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/gdm.h declares

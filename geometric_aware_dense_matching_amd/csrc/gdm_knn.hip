@@ -22,6 +22,15 @@
 //     insertion (~15-25 dependent wave instructions) for each of them.  Round 1's lane-distributed list
 //     spent 75 of its 93 wave instructions per 64 pairs on insertions; here the loop body is the distance
 //     (8 VALU) + one compare + one branch.
+//   * K > 1 against an ORGANISED support (a pixel grid of a depth map, gdm_knn_job.grid_w > 0; knn_grid_kernel): the points of one
+//     pixel column share x/z, those of one row y/z (pinhole projection), so the distance from a query to ANY point of a column is
+//     at least its distance to the plane through the origin that holds the column's rays: (x - a z)^2 / (1 + a^2), a = x'/z';
+//     likewise for rows.  A pre-kernel measures, per crop, the range [lo, hi] of that ratio over the valid pixels of every
+//     column and row (so nothing is ASSUMED about the data: an unstructured map just gets wide ranges and no pruning).  A query
+//     then takes its first 64 candidates around the column / row whose range holds its own ratio, and afterwards only scans
+//     the window of columns and rows whose lower bound is below its K-th distance: ~100 candidates instead of 16384, results
+//     identical to the exhaustive search (depth holes -- points at the origin -- are covered by a |q|^2 test that widens the
+//     window to the whole grid).
 //   * distances are ((dx*dx)+dy*dy)+dz*dz with every operation rounded to fp32 (no FMA
 //     contraction: __fmul_rn/__fadd_rn and -ffp-contract=off), exactly the reference's
 //     arithmetic, so indices are bit-exact on tie-free inputs; ties are ordered by ascending
@@ -48,6 +57,8 @@ struct KnnJobDev {
     int blocks_per_b;                   // blocks that cover the Q queries of one batch item
     int block_begin;                    // first blockIdx.x of this job
     const float4* packed;               // K > 1 only: the support set as hashed float4 tiles [B][ntiles][npad] (workspace), or null
+    const float* ranges;                // organised supports: per crop [col_lo W][col_hi W][row_lo H][row_hi H][bad, hole, -, -] (workspace)
+    int grid_w, grid_h;
 };
 
 struct KnnTable {
@@ -405,6 +416,251 @@ __global__ __launch_bounds__(KW_BLOCK) void knn_wave_kernel(const KnnTable tab)
     }
 }
 
+// ---- K > 1, organised support ---------------------------------------------------------------------------------------------
+constexpr int KG_MAXDIM = 256;          // grid width / height handled (4 columns or rows per lane)
+
+struct RangeEntry {
+    const float* support;
+    float* ranges;
+    long long support_bstride;
+    int W, H;
+    int nblocks;                        // B * ceil(H / 16)
+};
+
+struct RangeTable {
+    RangeEntry e[GDM_KNN_MAX_JOBS];
+    int n;
+    int B;
+};
+
+__host__ __device__ inline int range_floats(int W, int H) { return 2 * W + 2 * H + 4; }
+
+// Ratio ranges of every pixel column (x/z) and row (y/z) over the valid pixels (z > 0) of a crop.  The table is stored as ordered
+// unsigned keys so that every entry is a MAX reduction from an all-zero buffer (hipMemsetAsync): [key(-lo) | key(hi)] per column,
+// then per row, then two flag words: bad = a point with z <= 0 that is not the origin, or a non-finite coordinate (no pruning for
+// this crop); hole = a point at the origin.  One block per (entry, crop, 16 rows): rows are reduced inside the block, columns with
+// one atomicMax per column and block.
+__device__ __forceinline__ unsigned ord_key(float v)
+{
+    const unsigned u = (unsigned)__float_as_int(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);         // monotone float -> unsigned; 0 is below every real key
+}
+__device__ __forceinline__ float ord_val(unsigned k)           // inverse; key 0 (nothing recorded) -> -inf
+{
+    if (k == 0u) return -INFINITY;
+    return __int_as_float((int)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k));
+}
+
+constexpr int KG_ROWS = 16;
+
+__global__ __launch_bounds__(256) void knn_grid_ranges_kernel(const RangeTable tab)
+{
+    int blk = blockIdx.x, ei = 0;
+    while (ei + 1 < tab.n && blk >= tab.e[ei].nblocks) { blk -= tab.e[ei].nblocks; ++ei; }
+    const RangeEntry& e = tab.e[ei];
+    const int W = e.W, H = e.H;
+    const int chunks = (H + KG_ROWS - 1) / KG_ROWS;
+    const int b = blk / chunks, v0 = (blk - b * chunks) * KG_ROWS;
+    const float* sup = e.support + (long long)b * e.support_bstride;
+    unsigned* out = reinterpret_cast<unsigned*>(e.ranges) + (long long)b * range_floats(W, H);
+    const int tid = threadIdx.x;
+    unsigned flags = 0;
+    // rows v0 .. v0 + 15: 16 lanes per row
+    {
+        const int v = v0 + (tid >> 4), l = tid & 15;
+        float nlo = -INFINITY, hi = -INFINITY;                  // max of -a and of a
+        if (v < H)
+            for (int u = l; u < W; u += 16) {
+                const float* p = sup + ((long long)v * W + u) * 3;
+                const float x = p[0], y = p[1], z = p[2];
+                if (!(isfinite(x) && isfinite(y) && isfinite(z))) flags |= 1u;
+                else if (z > 0.f) {
+                    const float a = y / z;
+                    nlo = fmaxf(nlo, -a);
+                    hi = fmaxf(hi, a);
+                } else if (x == 0.f && y == 0.f && z == 0.f) flags |= 2u;
+                else flags |= 1u;
+            }
+        for (int m = 1; m < 16; m <<= 1) {
+            nlo = fmaxf(nlo, __shfl_xor(nlo, m, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+        }
+        if (v < H && l == 0) {
+            out[2 * W + v] = isinf(nlo) ? 0u : ord_key(nlo);
+            out[2 * W + H + v] = isinf(hi) ? 0u : ord_key(hi);
+        }
+    }
+    // columns: partial over this block's rows
+    for (int u = tid; u < W; u += 256) {
+        float nlo = -INFINITY, hi = -INFINITY;
+        for (int v = v0; v < min(v0 + KG_ROWS, H); ++v) {
+            const float* p = sup + ((long long)v * W + u) * 3;
+            const float x = p[0], z = p[2];
+            if (z > 0.f && isfinite(x) && isfinite(z)) {
+                const float a = x / z;
+                nlo = fmaxf(nlo, -a);
+                hi = fmaxf(hi, a);
+            }
+        }
+        if (!isinf(nlo)) atomicMax(out + u, ord_key(nlo));
+        if (!isinf(hi)) atomicMax(out + W + u, ord_key(hi));
+    }
+    if (__ballot(flags != 0u)) {
+        if (flags & 1u) atomicOr(out + 2 * W + 2 * H, 1u);
+        if (flags & 2u) atomicOr(out + 2 * W + 2 * H + 1, 1u);
+    }
+}
+
+// lower bound of the squared distance from (p, z) -- one coordinate and the depth of the query -- to any point whose ratio
+// coordinate / depth lies in [lo, hi]: 0 inside the range, else the nearer of the two bounding planes.  f(a) = (p - a z)^2 / (1 + a^2)
+// is unimodal away from a = p / z on either side up to the perpendicular direction and falls beyond it, so its minimum over an
+// interval that does not hold p / z is at an end point.  An empty range (lo > hi: no valid pixel) gives +inf.
+__device__ __forceinline__ float plane_bound(float p, float z, float lo, float hi)
+{
+    if (!(lo <= hi)) return INFINITY;
+    const float r = p / z;
+    if (r >= lo && r <= hi) return 0.f;
+    const float dl = p - lo * z, dh = p - hi * z;
+    return fminf(dl * dl / (1.f + lo * lo), dh * dh / (1.f + hi * hi));
+}
+
+__global__ __launch_bounds__(KW_BLOCK) void knn_grid_kernel(const KnnTable tab)
+{
+    __shared__ u64 cand[KW_WAVES][64];
+
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
+    const KnnJobDev& job = tab.jobs[j];
+    const int local = bid - job.block_begin;
+    const int b = local / job.blocks_per_b;
+    const int qb = local - b * job.blocks_per_b;
+    const int Q = job.Q, K = job.K, W = job.grid_w, H = job.grid_h;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = qb * KW_WAVES + wave;
+    if (q >= Q) return;                                   // wave-uniform; no block-level barrier in this kernel
+    const float* sup = job.support + (long long)b * job.support_bstride;
+    const float* qry = job.query + (long long)b * job.query_bstride + (long long)q * 3;
+    const float qx = qry[0], qy = qry[1], qz = qry[2];
+    const unsigned* rk = reinterpret_cast<const unsigned*>(job.ranges) + (long long)b * range_floats(W, H);
+    u64* buf = cand[wave];
+
+    float td = INFINITY;
+    int ti = IDX_EMPTY;
+    int cnt = 0;
+    auto compact = [&]() -> u64 {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        u64 key = lane < cnt ? buf[lane] : KEY_EMPTY;
+        wave_sort64(key, lane);
+        if (lane < K) buf[lane] = key;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cnt = min(cnt, K);
+        td = __int_as_float(__shfl((int)(unsigned)(key >> 32), K - 1, 64));
+        ti = __shfl((int)(unsigned)key, K - 1, 64);
+        return key;
+    };
+    // admission of one step's candidates; `incl`: the bound itself passes (second phase, after the buffer was emptied)
+    auto admit = [&](float d, int di, bool live, bool incl) {
+        bool pass = live && (lex_less(d, di, td, ti) || (incl && d == td && di == ti));
+        unsigned long long bal = __ballot(pass);
+        while (bal) {
+            const int n = __builtin_popcountll(bal);
+            if (cnt + n > 64 && cnt > K) {
+                compact();
+                pass = pass && (lex_less(d, di, td, ti) || (incl && d == td && di == ti));
+                bal = __ballot(pass);
+                continue;
+            }
+            const int room = 64 - cnt;
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            const bool now = pass && pos < room;
+            if (now) buf[cnt + pos] = make_key(d, di);
+            cnt += min(n, room);
+            pass = pass && !now;
+            bal = __ballot(pass);
+        }
+    };
+    auto eval = [&](int r, int c, bool live, bool incl) {  // grid cell (r, c) as a candidate
+        const int gi = live ? r * W + c : 0;
+        const float* p = sup + (long long)gi * 3;
+        admit(dist2_ref(qx, qy, qz, p[0], p[1], p[2]), gi, live, incl);
+    };
+
+    const bool structured = rk[2 * W + 2 * H] == 0u && qz > 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
+    const bool has_hole = rk[2 * W + 2 * H + 1] != 0u;
+    const float q2 = dist2_ref(qx, qy, qz, 0.f, 0.f, 0.f);
+    // this lane's columns lane, lane + 64, ... and rows: plane bounds (0 where the query's own ratio lies inside the range)
+    float lbc[KG_MAXDIM / 64], lbr[KG_MAXDIM / 64];
+#pragma unroll
+    for (int i = 0; i < KG_MAXDIM / 64; ++i) {
+        const int u = lane + 64 * i;
+        lbc[i] = (structured && u < W) ? plane_bound(qx, qz, -ord_val(rk[u]), ord_val(rk[W + u])) : (u < W ? 0.f : INFINITY);
+        lbr[i] = (structured && u < H) ? plane_bound(qy, qz, -ord_val(rk[2 * W + u]), ord_val(rk[2 * W + H + u])) : (u < H ? 0.f : INFINITY);
+    }
+    // centre cell: the column / row with the smallest bound (lowest index among equals)
+    auto arg_min = [&](const float (&lb)[KG_MAXDIM / 64]) {
+        float bv = lb[0];
+        int bi = lane;
+#pragma unroll
+        for (int i = 1; i < KG_MAXDIM / 64; ++i)
+            if (lb[i] < bv) { bv = lb[i]; bi = lane + 64 * i; }
+        for (int m = 1; m < 64; m <<= 1) {
+            const float ov = __shfl_xor(bv, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        return bi;
+    };
+    int c0 = 0, c1 = W - 1, r0 = 0, r1 = H - 1;
+    if (structured && W >= 8 && H >= 8) {
+        // phase 1: the 8 x 8 cells around the centre -> a first K-th distance
+        const int uc = min(max(arg_min(lbc) - 4, 0), W - 8), vc = min(max(arg_min(lbr) - 4, 0), H - 8);
+        eval(vc + (lane >> 3), uc + (lane & 7), true, false);
+        compact();
+        // phase 2: only columns / rows whose bound (less a rounding allowance, scale-free) can still be below the K-th distance
+        const float slack = 2e-6f * sqrtf(q2);
+        int cl = W, ch = -1, rl = H, rh = -1;
+#pragma unroll
+        for (int i = 0; i < KG_MAXDIM / 64; ++i) {
+            const int u = lane + 64 * i;
+            const float sc = sqrtf(lbc[i]) - slack, sr = sqrtf(lbr[i]) - slack;
+            const bool kc = u < W && (sc <= 0.f || sc * sc * 0.999f <= td);
+            const bool kr = u < H && (sr <= 0.f || sr * sr * 0.999f <= td);
+            if (kc) { cl = min(cl, u); ch = max(ch, u); }
+            if (kr) { rl = min(rl, u); rh = max(rh, u); }
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            cl = min(cl, __shfl_xor(cl, m, 64)); ch = max(ch, __shfl_xor(ch, m, 64));
+            rl = min(rl, __shfl_xor(rl, m, 64)); rh = max(rh, __shfl_xor(rh, m, 64));
+        }
+        const bool holes_matter = has_hole && q2 * 0.999f <= td;   // points at the origin lie outside every plane bound
+        if (!holes_matter && ch >= cl && rh >= rl) { c0 = cl; c1 = ch; r0 = rl; r1 = rh; }
+        cnt = 0;                                          // the window holds the K best again: start over, bound inclusive
+    }
+    const bool incl = structured && W >= 8 && H >= 8;
+    const int wc = c1 - c0 + 1, total = wc * (r1 - r0 + 1);
+    const float inv_wc = 1.f / (float)wc;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        const int e = e0 + lane;
+        int r = (int)((float)e * inv_wc);                 // e / wc, corrected for the float estimate
+        r -= (r * wc > e);
+        r += ((r + 1) * wc <= e);
+        const int c = e - r * wc;
+        eval(r0 + r, c0 + c, e < total, incl);
+    }
+    const u64 key = compact();
+    if (lane < K) {
+        const long long o = ((long long)b * Q + q) * K + lane;
+        const int si = (int)(unsigned)key;
+        const float sd = __int_as_float((int)(unsigned)(key >> 32));
+        job.idx[o] = si == IDX_EMPTY ? 0 : si;
+        if (job.d2) job.d2[o] = isinf(sd) ? 3.402823466e+38f : sd;
+    }
+}
+
 int pick_logT(int S)
 {
     // every lane scans >= 128 support points where possible; T in {1,2,...,64}
@@ -425,6 +681,8 @@ void fill_job(KnnJobDev& d, const gdm_knn_job& j)
     d.Q = j.Q;
     d.K = j.K;
     d.packed = nullptr;
+    d.ranges = nullptr;
+    d.grid_w = d.grid_h = 0;
 }
 
 // K == 1 jobs: per-lane best + shuffle merge
@@ -455,13 +713,27 @@ size_t packed_bytes(int S, int B)
     return (size_t)B * ntiles * npad * sizeof(float4);
 }
 
+bool is_grid_job(const gdm_knn_job& j)
+{
+    const int W = j.grid_w;
+    return j.K > 1 && W > 0 && j.S % W == 0 && W <= KG_MAXDIM && j.S / W <= KG_MAXDIM && W >= 8 && j.S / W >= 8;
+}
+
+size_t ranges_bytes(const gdm_knn_job& j, int B) { return (size_t)B * range_floats(j.grid_w, j.S / j.grid_w) * sizeof(float); }
+
+bool same_support(const gdm_knn_job& a, const gdm_knn_job& b)
+{
+    return a.support == b.support && a.S == b.S && a.support_bstride == b.support_bstride;
+}
+
 // K in [2, 32] jobs: one query per wave.  Large jobs first, so that the tail of the launch is made of short blocks.
-// With a workspace every distinct support set is re-laid out once (knn_pack_kernel) and shared by the jobs that search it.
+// With a workspace every distinct unorganised support set is re-laid out once (knn_pack_kernel) and shared by the jobs that search
+// it, and the searches against organised supports (grid_w > 0) run as window searches (knn_grid_ranges_kernel + knn_grid_kernel).
 int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    KnnTable tab;
-    tab.njobs = 0;
-    tab.B = B;
+    KnnTable tab, gtab;
+    tab.njobs = gtab.njobs = 0;
+    tab.B = gtab.B = B;
     int order[GDM_KNN_MAX_JOBS], n = 0;
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].K > 1) order[n++] = i;
@@ -475,11 +747,51 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
     PackTable pk;
     pk.n = 0;
     pk.B = B;
-    int pack_blocks = 0;
-    size_t used = 0;
-    int nblocks = 0;
+    RangeTable rt;
+    rt.n = 0;
+    rt.B = B;
+    const gdm_knn_job* rt_job[GDM_KNN_MAX_JOBS];
+    const gdm_knn_job* pk_job[GDM_KNN_MAX_JOBS];
+    int pack_blocks = 0, range_blocks = 0;
+    size_t used = 0, range_first = 0, range_last = 0;
+    int nblocks = 0, gblocks = 0;
     for (int a = 0; a < n; ++a) {
         const gdm_knn_job& jb = jobs[order[a]];
+        if (workspace && is_grid_job(jb)) {               // organised support: window search
+            int e = 0;
+            while (e < rt.n && !same_support(*rt_job[e], jb)) ++e;
+            bool ok = e < rt.n;
+            if (!ok) {
+                const size_t need = (ranges_bytes(jb, B) + 15) & ~(size_t)15;
+                if (used + need <= workspace_bytes) {
+                    RangeEntry& re = rt.e[rt.n];
+                    re.support = jb.support;
+                    re.support_bstride = jb.support_bstride;
+                    re.W = jb.grid_w;
+                    re.H = jb.S / jb.grid_w;
+                    re.ranges = (float*)((char*)workspace + used);
+                    re.nblocks = B * gdm_cdiv(re.H, KG_ROWS);
+                    if (rt.n == 0) range_first = used;
+                    range_last = used + need;
+                    range_blocks += re.nblocks;
+                    rt_job[rt.n++] = &jb;
+                    used += need;
+                    ok = true;
+                }
+            }
+            if (ok) {
+                KnnJobDev& d = gtab.jobs[gtab.njobs++];
+                fill_job(d, jb);
+                d.logT = 0;
+                d.grid_w = jb.grid_w;
+                d.grid_h = jb.S / jb.grid_w;
+                d.ranges = rt.e[e].ranges;
+                d.blocks_per_b = gdm_cdiv(d.Q, KW_WAVES);
+                d.block_begin = gblocks;
+                gblocks += d.blocks_per_b * B;
+                continue;
+            }
+        }
         KnnJobDev& d = tab.jobs[tab.njobs++];
         fill_job(d, jb);
         d.logT = 0;
@@ -488,11 +800,11 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
         nblocks += d.blocks_per_b * B;
         if (!workspace) continue;
         int e = 0;                                        // a support set already packed for an earlier job?
-        while (e < pk.n && !(pk.e[e].support == jb.support && pk.e[e].S == jb.S && pk.e[e].support_bstride == jb.support_bstride)) ++e;
+        while (e < pk.n && !same_support(*pk_job[e], jb)) ++e;
         if (e == pk.n) {
             const size_t need = packed_bytes(jb.S, B);
             if (used + need > workspace_bytes) continue;  // does not fit: this job fills its tiles from the [S][3] array
-            PackEntry& pe = pk.e[pk.n++];
+            PackEntry& pe = pk.e[pk.n];
             pe.support = jb.support;
             pe.support_bstride = jb.support_bstride;
             pe.S = jb.S;
@@ -500,17 +812,32 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
             pe.packed = (float4*)((char*)workspace + used);
             pe.block_begin = pack_blocks;
             pack_blocks += (int)gdm_cdiv((long)B * pe.ntiles * pe.npad, 256);
+            pk_job[pk.n++] = &jb;
             used += need;
         }
         d.packed = pk.e[e].packed;
     }
+    int rc;
+    if (rt.n) {
+        // every entry of the range tables is a max-reduction from zero (packed tiles may sit between two tables: they are
+        // written afterwards by knn_pack_kernel, so clearing the whole span is harmless)
+        GDM_HIP(hipMemsetAsync((char*)workspace + range_first, 0, range_last - range_first, stream));
+        hipLaunchKernelGGL(knn_grid_ranges_kernel, dim3(range_blocks), dim3(256), 0, stream, rt);
+        if ((rc = gdm_launch_status("knn_grid_ranges_kernel"))) return rc;
+    }
     if (pk.n) {
         hipLaunchKernelGGL(knn_pack_kernel, dim3(pack_blocks), dim3(256), 0, stream, pk);
-        const int rc = gdm_launch_status("knn_pack_kernel");
-        if (rc) return rc;
+        if ((rc = gdm_launch_status("knn_pack_kernel"))) return rc;
     }
-    hipLaunchKernelGGL(knn_wave_kernel, dim3(nblocks), dim3(KW_BLOCK), 0, stream, tab);
-    return gdm_launch_status("knn_wave_kernel");
+    if (tab.njobs) {
+        hipLaunchKernelGGL(knn_wave_kernel, dim3(nblocks), dim3(KW_BLOCK), 0, stream, tab);
+        if ((rc = gdm_launch_status("knn_wave_kernel"))) return rc;
+    }
+    if (gtab.njobs) {
+        hipLaunchKernelGGL(knn_grid_kernel, dim3(gblocks), dim3(KW_BLOCK), 0, stream, gtab);
+        if ((rc = gdm_launch_status("knn_grid_kernel"))) return rc;
+    }
+    return 0;
 }
 
 } // namespace
@@ -538,9 +865,9 @@ extern "C" size_t gdm_knn_jobs_workspace_bytes(const gdm_knn_job* jobs, int njob
         if (jobs[i].K <= 1) continue;
         bool seen = false;
         for (int e = 0; e < i && !seen; ++e)
-            seen = jobs[e].K > 1 && jobs[e].support == jobs[i].support && jobs[e].S == jobs[i].S &&
-                   jobs[e].support_bstride == jobs[i].support_bstride;
-        if (!seen) total += packed_bytes(jobs[i].S, B);
+            seen = jobs[e].K > 1 && same_support(jobs[e], jobs[i]) && is_grid_job(jobs[e]) == is_grid_job(jobs[i]);
+        if (seen) continue;
+        total += is_grid_job(jobs[i]) ? ((ranges_bytes(jobs[i], B) + 15) & ~(size_t)15) : packed_bytes(jobs[i].S, B);
     }
     return total;
 }
@@ -575,7 +902,7 @@ extern "C" int gdm_knn_batch_hip(const float* support, const float* query, int B
     j.S = S;
     j.Q = Q;
     j.K = K;
-    j._pad = 0;
+    j.grid_w = 0;
     return gdm_knn_jobs_hip(&j, 1, B, stream);
 }
 

@@ -108,14 +108,17 @@ def knn_batch(support, query, K, return_d2=False):
 
 
 def knn_jobs(jobs, B):
-    """jobs: list of (support f32 view [B,S,3], query f32 view [B,Q,3], K).  Views may be prefix
-    slices along dim 1 of contiguous [B,N,3] arrays (batch stride kept).  One launch per K class.
-    Returns the list of idx tensors i32[B,Q,K]."""
+    """jobs: list of (support f32 view [B,S,3], query f32 view [B,Q,3], K[, grid_w]).  Views may be prefix
+    slices along dim 1 of contiguous [B,N,3] arrays (batch stride kept).  grid_w > 0 declares the support an organised map of
+    S / grid_w rows x grid_w columns (row-major pixels of a depth crop): K > 1 searches then scan only the window of pixel
+    columns / rows that can hold a neighbour (same results).  One launch per K class.  Returns the idx tensors i32[B,Q,K]."""
     n = len(jobs)
     arr = (KnnJob * n)()
     outs = []
     keep = []
-    for i, (sup, qry, K) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        sup, qry, K = job[:3]
+        grid_w = int(job[3]) if len(job) > 3 else 0
         for t, nm in ((sup, "support"), (qry, "query")):
             if not t.is_cuda or t.dtype != torch.float32:
                 raise RuntimeError("knn_jobs: %s must be a CUDA float32 tensor" % nm)
@@ -131,6 +134,7 @@ def knn_jobs(jobs, B):
         arr[i].support_bstride = sup.stride(0) if B > 1 else S * 3
         arr[i].query_bstride = qry.stride(0) if B > 1 else Q * 3
         arr[i].S, arr[i].Q, arr[i].K = S, Q, K
+        arr[i].grid_w = grid_w if (grid_w > 0 and S % grid_w == 0) else 0
         outs.append(out)
         keep.append((sup, qry))
     _knn_launch(arr, n, B, jobs[0][0].device)

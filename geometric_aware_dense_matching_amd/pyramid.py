@@ -60,11 +60,11 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
     jobs, names = [], []
     for i in range(4):
         cur, sub, px = levels[i], levels[i + 1], grids[RGB_DS_SR[i]]
-        jobs += [(cur, cur, K_NEI), (sub, cur, 1), (px, sub, K_NEI), (sub, px, 1)]
+        jobs += [(cur, cur, K_NEI), (sub, cur, 1), (px, sub, K_NEI, S // RGB_DS_SR[i]), (sub, px, 1)]     # px: an S/sr-wide pixel grid
         names += ["cld_nei_idx%d" % i, "cld_interp_idx%d" % i, "r2p_ds_nei_idx%d" % i, "p2r_ds_nei_idx%d" % i]
     for i in range(3):
         pts, px = levels[3 - i], grids[RGB_UP_SR[i]]
-        jobs += [(px, pts, K_NEI), (pts, px, 1)]
+        jobs += [(px, pts, K_NEI, S // RGB_UP_SR[i]), (pts, px, 1)]
         names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
     outs = ops.knn_jobs(jobs, B)
 

@@ -59,7 +59,10 @@ typedef struct gdm_knn_job {
     float* d2;                /* f32[B,Q,K] dense, or NULL */
     int64_t support_bstride;  /* in floats; S*3 when dense. A prefix slice cld[:, :S] of a  */
     int64_t query_bstride;    /* [B,N,3] array keeps bstride N*3 (linemod_pbr.py:538)     */
-    int32_t S, Q, K, _pad;
+    int32_t S, Q, K;
+    int32_t grid_w;           /* 0, or: the support is an ORGANISED map (e.g. the xyz of a depth crop) of S / grid_w rows x grid_w columns
+                               * in row-major pixel order -- a hint that lets K > 1 searches with a workspace prune by pixel columns / rows;
+                               * results are identical with and without it, for any data                                            */
 } gdm_knn_job;
 #define GDM_KNN_MAX_JOBS 32
 int gdm_knn_jobs_hip(const gdm_knn_job* jobs /* host array */, int njobs, int B, void* stream);

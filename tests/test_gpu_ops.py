@@ -84,6 +84,63 @@ def test_knn_jobs_prefix_views(ops):
         assert np.array_equal(got.cpu().numpy().astype(np.int64), oknn.knn_batch(a, b, k))
 
 
+def _depth_grid(rs, B, H, W, scale=1.0, holes=0.05, step_edge=True):
+    """xyz map [B,H*W,3] of a pinhole depth image: smooth surface + a depth discontinuity + zero holes (points at the origin)."""
+    v, u = np.mgrid[:H, :W].astype(np.float32)
+    out = np.zeros((B, H * W, 3), np.float32)
+    for b in range(B):
+        z = 0.8 + 0.1 * np.sin(u / 7.0 + b) * np.cos(v / 5.0) + (rs.rand(H, W).astype(np.float32) - 0.5) * 2e-3
+        if step_edge:
+            z[:, W // 2:] += 0.35                           # a foreground / background edge
+        z[rs.rand(H, W) < holes] = 0.0
+        x = (u - W / 2.0 + 0.37) * z / (1.2 * W)
+        y = (v - H / 2.0 - 0.21) * z / (1.2 * W)
+        out[b] = (np.stack([x, y, z], axis=2) * (z > 0)[:, :, None]).reshape(-1, 3) * scale
+    return out
+
+
+@pytest.mark.parametrize("H,W,K,Q,scale", [(64, 64, 16, 512, 1.0), (128, 128, 16, 128, 1.0), (24, 40, 5, 77, 1.0), (32, 32, 16, 8, 1000.0),
+                                           (64, 64, 32, 200, 1.0)])
+def test_knn_organised_support_window_search_equals_brute_force(ops, H, W, K, Q, scale):
+    """gdm_knn_job.grid_w: the window search over pixel columns / rows (plane bounds from measured x/z, y/z ranges) gives the
+    indices and distances of the exhaustive search -- queries on the surface, off the surface, next to the depth edge, behind
+    holes; metres and millimetres; grids that are not square."""
+    from oracle import knn as oknn
+    rs = np.random.RandomState(H * 3 + W + K)
+    B = 3
+    sup = _depth_grid(rs, B, H, W, scale)
+    pick = rs.randint(0, H * W, size=(B, Q))
+    qry = np.stack([sup[b][pick[b]] for b in range(B)]) + (rs.randn(B, Q, 3) * 0.003 * scale).astype(np.float32)
+    qry[:, : Q // 8] += (rs.randn(B, Q // 8, 3) * 0.2 * scale).astype(np.float32)        # some queries far from the surface
+    qry = qry.astype(np.float32)
+    want, want_d2 = oknn.knn_batch(sup, qry, K, return_d2=True)
+    s_t, q_t = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    got = ops.knn_jobs([(s_t, q_t, K, W)], B)[0].cpu().numpy()
+    plain = ops.knn_jobs([(s_t, q_t, K)], B)[0].cpu().numpy()
+    # holes are exact duplicates (all at the origin): compare distances, and indices wherever the distance is unique in the list
+    d2 = lambda idx: np.stack([oknn.d2_of(sup[b], qry[b], idx[b]) for b in range(B)])
+    assert np.array_equal(d2(got), want_d2) and np.array_equal(d2(plain), want_d2)
+    assert np.array_equal(got, plain)                                   # canonical (d2, index) order on both paths
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_knn_organised_hint_on_unstructured_data_is_still_exact(ops):
+    """The hint is never trusted: a random cloud declared as a grid (ranges wide, no pruning), a map with negative depths (pruning
+    switched off for the crop) and an all-hole map give the exhaustive search's result."""
+    from oracle import knn as oknn
+    rs = np.random.RandomState(5)
+    B, H, W, K, Q = 2, 32, 48, 16, 100
+    cases = [rs.rand(B, H * W, 3).astype(np.float32) - 0.5, _depth_grid(rs, B, H, W), np.zeros((B, H * W, 3), np.float32)]
+    cases[1][:, ::7, 2] *= -1.0
+    qry = (rs.rand(B, Q, 3).astype(np.float32) - 0.5)
+    for sup in cases:
+        want_d2 = oknn.knn_batch(sup, qry, K, return_d2=True)[1]
+        got = ops.knn_jobs([(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), K, W)], B)[0].cpu().numpy()
+        plain = ops.knn_jobs([(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), K)], B)[0].cpu().numpy()
+        assert np.array_equal(got, plain)
+        assert np.array_equal(np.stack([oknn.d2_of(sup[b], qry[b], got[b]) for b in range(B)]), want_d2)
+
+
 def _feat_idx(rs, B, C, n, m, K):
     feat = torch.from_numpy(rs.randn(B, C, n).astype(np.float32))
     idx = torch.from_numpy(rs.randint(0, n, size=(B, m, K)).astype(np.int64))
