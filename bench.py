@@ -276,7 +276,21 @@ def extra_legs(torch, dev, args, model, N, M):
         ms = (time.perf_counter() - t0) / 3 * 1e3
         out["train"] = {"train_ms_per_step": round(ms, 2), "crops_per_s": round(Bt / ms * 1e3, 1), "batch": Bt, "n_points": Nt, "n_model": Mt,
                         "what": "fwd + losses + bwd + Adam on one GPU (per-GPU work of config 3 without the RCCL all-reduce)"}
-        del tm, opt
+        # the same iteration as ONE hipGraph launch (train_graph.GraphedTrainStep): the host enqueues 1 launch instead of ~1 900
+        from geometric_aware_dense_matching_amd.train_graph import GraphedTrainStep
+        batch_host = torch.utils.data.default_collate([ds[i] for i in range(Bt)])
+        gs = GraphedTrainStep(tm, opt, dev, warmup=1)
+        for _ in range(3):
+            gs.step(batch_host)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gs.step(batch_host)
+        t_host = (time.perf_counter() - t0) / 3 * 1e3
+        torch.cuda.synchronize()
+        msg = (time.perf_counter() - t0) / 3 * 1e3
+        out["train"].update(graphed_ms_per_step=round(msg, 2), graphed_host_ms_per_step=round(t_host, 2), graphed_launches_per_step=1)
+        del tm, opt, gs
     finally:
         torch.backends.cudnn.benchmark = find
     torch.cuda.empty_cache()

@@ -345,8 +345,22 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// pixel fragments (16 pixels each) per wave: 2 = eight waves of 32 pixels (two waves per SIMD), 4 = four waves of 64 pixels (one
+// wave per SIMD, 512 registers): every B fragment read from LDS then feeds twice the MFMAs and no partner wave competes for the
+// matrix pipe; the per-panel barrier joins four waves instead of eight.
+#ifndef GDM_CONV_NPH
+#define GDM_CONV_NPH 2
+#endif
+constexpr int MF_NPH = GDM_CONV_NPH;
+constexpr int MF_WPIX = 16 * MF_NPH;                  // pixels per wave
+constexpr int MF_WAVES = CV_PIX / MF_WPIX;
+constexpr int MF_THREADS = MF_WAVES * 64;
+constexpr int MF_STAGE = 4096 / MF_THREADS;           // 16-byte chunks of a weight panel per thread
+constexpr int MF_TSTRIDE = 132;                       // floats per pixel row of a wave's output tile in LDS (128 + 4: conflict-free reads)
+constexpr int MF_SMEM = 2 * CV_PANEL > CV_PIX * MF_TSTRIDE * 4 ? 2 * CV_PANEL : CV_PIX * MF_TSTRIDE * 4;
+
 template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8>
-__global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
+__global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
                                                                  float* __restrict__ out, const int32_t* __restrict__ rowidx = nullptr,
@@ -355,25 +369,28 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     constexpr int NS = NKS / 2;                                     // k-steps of 32 channels per chunk
+    constexpr int NPH = MF_NPH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;                      // row inside a 16-row fragment, 8-channel group inside a k-step
     const int nchunk = (Cin + 127) / 128;
     const int npanel = TAPS * nchunk;
     const int hw = H * W;
-    const long ptot = rowidx ? (long)B : (long)B * hw;
-    const long pix0 = (long)blockIdx.x * CV_PIX + wave * 32;
+    const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
+    const long pix0 = (long)blockIdx.x * CV_PIX + wave * MF_WPIX;   // this wave's first pixel
     const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * CV_CO;
-    const long pc = min(pix0, ptot - 32);
-    const int b = (int)(pc / hw);
+    const long pc = min(pix0, ptot - MF_WPIX);
+    const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
     const int prem = (int)(pc - (long)b * hw);
-    const int y = prem / W, x0 = prem - y * W;
     const long plane = (long)(H + 2) * (W + 2);
-    long pixbase[2];
+    long pixbase[NPH];                                              // fragment ph: 16 consecutive pixels of one image row (W % 16 == 0)
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-        pixbase[ph] = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)y * (W + 2) + x0 + l16 + 16 * ph;
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int pr = prem + 16 * ph;
+        const int yy = pr / W, xx = pr - yy * W;
+        pixbase[ph] = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)yy * (W + 2) + xx + l16;
+    }
 
-    u32x4 ahi[NS][2], alo[NS][2];                                   // fragments of k-step S, pixel half ph
+    u32x4 ahi[NS][NPH], alo[NS][NPH];                               // fragments of k-step S, pixel fragment ph
     auto a_row = [&](int it) {                                      // plane kg of the panel's chunk, tap-shifted, pixel 0
         const int tap = (TAPS == 1) ? 4 : it / nchunk;
         const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
@@ -384,32 +401,32 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
     const long lostride = 16 * plane * 16;                          // hi plane q -> lo plane 16 + q
     auto load_a = [&](const unsigned char* r, int S) {
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = 0; ph < NPH; ++ph) {
             ahi[S][ph] = *reinterpret_cast<const u32x4*>(r + S * sstride + pixbase[ph] * 16);
             alo[S][ph] = *reinterpret_cast<const u32x4*>(r + S * sstride + lostride + pixbase[ph] * 16);
         }
     };
-    u32x4 stage[8];
+    u32x4 stage[MF_STAGE];
     auto stage_load = [&](int it) {
         const unsigned char* src = wpk + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = i * CV_THREADS + tid;
+        for (int i = 0; i < MF_STAGE; ++i) {
+            const int g = i * MF_THREADS + tid;
             stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
         }
     };
     auto stage_store = [&](int buf) {
         unsigned char* base = smem + buf * CV_PANEL;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = i * CV_THREADS + tid;
+        for (int i = 0; i < MF_STAGE; ++i) {
+            const int g = i * MF_THREADS + tid;
             *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
         }
     };
 
-    f32x4 acc[2][8];
+    f32x4 acc[NPH][8];
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
         const unsigned char* rcur = a_row(it);
         const unsigned char* rnext = a_row(more ? it + 1 : it);
         const unsigned char* base = smem + (it & 1) * CV_PANEL;
-        // units of (k-step S, pair of 16-channel output blocks): 12 MFMAs of 16 cycles on 4 B fragments; PF units' reads in flight
+        // units of (k-step S, pair of 16-channel output blocks): 6 NPH MFMAs of 16 cycles on 4 B fragments; PF units' reads in flight
         constexpr int PF = 2;
         constexpr int NU = 4 * NS;
         u32x4 fh[PF + 1][2], fl[PF + 1][2];
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
             const int S = u >> 2, pr = u & 3, slot = u % (PF + 1);
             if (u + PF < NU) frag_load(u + PF);
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
+            for (int ph = 0; ph < NPH; ++ph) {
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[S][ph]);
                 const bf16x8 al = __builtin_bit_cast(bf16x8, alo[S][ph]);
 #pragma unroll
@@ -468,9 +485,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
                 for (int S2 = NS - LATE; S2 < NS; ++S2) load_a(rcur, S2);
             }
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < 6 * NPH; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u + PF < NU && (i & 1) == 0 && i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (u + PF < NU && (i % NPH) == 0 && i < 4 * NPH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -488,7 +505,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
             const int ocol = tile_co0 ? cb * 16 + l16 : co;
             const int ostride = tile_co0 ? CV_CO : Cout;
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph)
+            for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[ph][cb][r] * sc + sh;
@@ -498,8 +515,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
         }
         return;
     }
-    constexpr int TSTRIDE = 132;
-    float* tl = reinterpret_cast<float*>(smem) + wave * 32 * TSTRIDE;
+    float* tl = reinterpret_cast<float*>(smem) + wave * MF_WPIX * MF_TSTRIDE;
     if (outpk) __syncthreads();                                      // every wave has finished reading the last weight panel
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
         float* op = out ? out + ((long)b * Cout + (live ? co : 0)) * hw + prem : nullptr;
         const float* rp = (HAS_RES && live) ? res + ((long)b * Cout + co) * hw + prem : nullptr;
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = 0; ph < NPH; ++ph) {
             const int poff = 16 * ph + 4 * kg;
             float v[4];
 #pragma unroll
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
             if (op && live) *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
             if (outpk) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tl[(poff + j) * TSTRIDE + cb * 16 + l16] = live ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) tl[(poff + j) * MF_TSTRIDE + cb * 16 + l16] = live ? v[j] : 0.f;
             }
         }
     }
@@ -534,18 +550,24 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
         const int lr = lane & 31, h = lane >> 5;
         const int ochunks = (Cout + 127) / 128;
         const int ochunk = co0 / 128;
-        unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * plane + (long)(y + 1) * (W + 2) + x0 + lr + 1) * 16;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int q = 2 * it + h;
-            if (co0 + q * 8 >= Cout) continue;
-            const float4 a0 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8 + 4);
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            unsigned hi[4], lo[4];
-            split8(v, hi, lo);
-            *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        for (int half = 0; half < MF_WPIX / 32; ++half) {
+            const int pp = prem + 32 * half + lr;                    // this lane's pixel of the wave's tile
+            const int yy = pp / W, xx = pp - yy * W;
+            unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * plane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
+            const float* row = tl + (32 * half + lr) * MF_TSTRIDE;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int q = 2 * it + h;
+                if (co0 + q * 8 >= Cout) continue;
+                const float4 a0 = *reinterpret_cast<const float4*>(row + q * 8);
+                const float4 a1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                unsigned hi[4], lo[4];
+                split8(v, hi, lo);
+                *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
         }
     }
 }
@@ -556,8 +578,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma16_kernel(const unsigned 
 #endif
 #if GDM_CONV_SHAPE == 16
 #define CONV_KERNEL conv_mfma16_kernel
+constexpr int CONV_THREADS = MF_THREADS, CONV_WPIX = MF_WPIX, CONV_SMEM = MF_SMEM;
 #else
 #define CONV_KERNEL conv3x3_bf16x3_kernel
+constexpr int CONV_THREADS = CV_THREADS, CONV_WPIX = 32, CONV_SMEM = 2 * CV_PANEL > 8 * 32 * 132 * 4 ? 2 * CV_PANEL : 8 * 32 * 132 * 4;
 #endif
 
 } // namespace
@@ -618,14 +642,15 @@ extern "C" int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const f
 {
     GDM_CHECK_ARG(xpk && wpk && (out || outpk), "gdm_conv3x3_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
-    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && ((long)B * H * W) % 32 == 0, "gdm_conv3x3_packed_hip: W=%d must be a multiple of 32", W);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CONV_WPIX == 0,
+                  "gdm_conv3x3_packed_hip: W=%d must be a multiple of 32 and H*W=%d of %d", W, H * W, CONV_WPIX);
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv3x3_packed_hip: act=%d", act);
     GDM_CHECK_ARG(!outpk || (Cout % 8 == 0 && ((long)B * H * W) % CV_PIX == 0),
                   "gdm_conv3x3_packed_hip: packed output needs Cout %% 8 == 0 and B*H*W %% 256 == 0 (got Cout=%d, B*H*W=%ld)", Cout, (long)B * H * W);
     const long ptot = (long)B * H * W;
     dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));
     hipStream_t s = (hipStream_t)stream;
-    constexpr int SMEM = 2 * CV_PANEL > 8 * 32 * 132 * 4 ? 2 * CV_PANEL : 8 * 32 * 132 * 4;      // panels, or the eight waves' output tiles
+    constexpr int SMEM = CONV_SMEM;                                 // weight panels, or the waves' output tiles
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)CONV_KERNEL<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -638,7 +663,7 @@ extern "C" int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const f
         (void)hipFuncSetAttribute((const void*)CONV_KERNEL<1, true, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr = true;
     }
-#define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
+#define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
     if (Cin == 64) {                                             // one half-filled chunk: only its four non-zero k-steps are run
         if (act == 0) { if (res) CV(0, true, 4); else CV(0, false, 4); }
         else { if (res) CV(1, true, 4); else CV(1, false, 4); }
@@ -670,7 +695,7 @@ extern "C" int gdm_gemm_grouped_hip(const void* xpk, const void* wpk, const int3
         attr = true;
     }
     // the kernel sees B = R "pixels" of a 1 x 1 map for the row bookkeeping and H = 1, W = M for the packed source
-    hipLaunchKernelGGL((CONV_KERNEL<0, false, 1, true>), dim3(R / CV_PIX, 1), dim3(CV_THREADS), 2 * CV_PANEL, (hipStream_t)stream,
+    hipLaunchKernelGGL((CONV_KERNEL<0, false, 1, true>), dim3(R / CV_PIX, 1), dim3(CONV_THREADS), 2 * CV_PANEL, (hipStream_t)stream,
                        (const unsigned char*)xpk, (const unsigned char*)wpk, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        R, Cin, Cout_total, 1, M, out, rowidx, tile_co0);
     return gdm_launch_status("gemm_grouped_kernel");
@@ -684,7 +709,8 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
     GDM_CHECK_ARG(Cin != 64 || !pixel_major, "gdm_conv1x1_packed_hip: Cin=64 is built for the NCHW output only");
-    GDM_CHECK_ARG(W % 32 == 0 && H >= 1, "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32", W);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CONV_WPIX == 0,
+                  "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32 and H*W=%d of %d", W, H * W, CONV_WPIX);
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
     dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));       // the last block's rows beyond Cout are zero weights, never stored
@@ -700,12 +726,12 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
         attr = true;
     }
     if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
-#define C1H(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 4>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+#define C1H(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 4>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
         if (act == 0) C1H(0); else C1H(1);
 #undef C1H
         return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
-#define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+#define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
     if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }
     else { if (pixel_major) C1(1, true); else C1(1, false); }
 #undef C1

@@ -75,11 +75,20 @@ class GeoMatch(nn.Module):
         counts = sel.sum(dim=1)
         item_ok = counts >= 3                                      # geoMatch.py:126-127
         sel = sel & item_ok.unsqueeze(1)
-        bi, pi = torch.nonzero(sel, as_tuple=True)                 # row-major: item, then point order
-        if bi.numel() == 0:
-            return torch.zeros((), device=mesh.device)
+        # The selected rows are compacted with one host read of their count; under a hipGraph capture (train_graph.py) nothing
+        # may depend on the host, so there every one of the B*N rows is run and the unselected ones get weight zero.
+        static_rows = settings.STATIC_MATCH_ROWS or torch.cuda.is_current_stream_capturing()
+        if static_rows:
+            bi = torch.arange(B, device=mesh.device).repeat_interleave(N)
+            pi = torch.arange(N, device=mesh.device).repeat(B)
+        else:
+            bi, pi = torch.nonzero(sel, as_tuple=True)             # row-major: item, then point order
+            if bi.numel() == 0:
+                return torch.zeros((), device=mesh.device)
         rows = F.normalize(rgbd_feature.transpose(1, 2)[bi, pi], p=2, dim=1)      # [R,128]
         match_all = x["match_idx"].long()
+        if static_rows:
+            match_all = match_all.clamp(0, M)                      # M = "no correspondence"; an unselected row's entry may be anything
         symmetric = self.model_emb.sys_corr_idx is not None
         if symmetric:
             if N != M:
@@ -109,6 +118,10 @@ class GeoMatch(nn.Module):
                 lrow = self.circle_loss.rows(sim, mask, 0.2)
             else:
                 lrow = ops.circle_rows(sim, c1, bi, self.model_emb.xyz.contiguous(), x["visible_flag"], self.positive_r, 16.0, 0.2)
+        if static_rows:
+            per_item = (lrow.view(B, N) * sel.to(lrow.dtype)).sum(dim=1) / counts.clamp(min=1).to(torch.float32)
+            ok = item_ok.to(torch.float32)
+            return (per_item * ok).sum() / ok.sum().clamp(min=1.0)
         per_item = torch.zeros(B, dtype=torch.float32, device=mesh.device).index_add_(0, bi, lrow)
         per_item = per_item[item_ok] / counts[item_ok].to(torch.float32)
         return per_item.mean()

@@ -75,6 +75,8 @@ def build_parser():
     p.add_argument("--single-object", action="store_true", help="test: only -cls_id instead of every object of the dataset")
     p.add_argument("--graph-batch1", action="store_true",
                    help="test: per-object hipGraph replay for single-instance groups (a batch-1 eager step is launch-bound)")
+    p.add_argument("--graph-train", action="store_true",
+                   help="train: capture one iteration (forward + losses + backward + Adam) as a hipGraph and replay it (single process)")
     return p
 
 
@@ -152,8 +154,9 @@ class Trainer:
     """train_lm.py:178-296."""
 
     def __init__(self, model, optimizer, checkpoint_dir, obj_name, lr_scheduler=None, bnm_scheduler=None, device=None,
-                 local_rank=0, save_every=10, log_every=100):
+                 local_rank=0, save_every=10, log_every=100, graphed_step=None):
         self.model, self.optimizer = model, optimizer
+        self.graphed_step = graphed_step                     # train_graph.GraphedTrainStep: the iteration as one hipGraph launch
         self.lr_scheduler, self.bnm_scheduler = lr_scheduler, bnm_scheduler
         self.checkpoint_dir, self.obj_name = checkpoint_dir, obj_name
         self.device, self.local_rank, self.save_every, self.log_every = device, local_rank, save_every, log_every
@@ -172,7 +175,10 @@ class Trainer:
                 t0 = time.time()
                 for it, batch in enumerate(train_loader):
                     self.model.train()
-                    out, _ = model_fn_dec(self.model, batch, self.device)
+                    if self.graphed_step is not None:
+                        out = self.graphed_step.step(batch)      # forward, backward and optimizer.step() in one launch
+                    else:
+                        out, _ = model_fn_dec(self.model, batch, self.device)
                     loss = out["loss"]
                     vals = torch.stack([loss.detach().float(), out["seg_loss"].detach().float(),
                                         torch.as_tensor(out["match_loss"], device=loss.device).detach().float()])
@@ -184,9 +190,10 @@ class Trainer:
                                 *(sums / self.log_every).tolist(), time.time() - t0))
                         sums = None
                         t0 = time.time()
-                    loss.backward()
-                    self.optimizer.step()
-                    self.optimizer.zero_grad()
+                    if self.graphed_step is None:
+                        loss.backward()
+                        self.optimizer.step()
+                        self.optimizer.zero_grad()
                     if self.lr_scheduler is not None:
                         self.lr_scheduler.step()
                     if self.bnm_scheduler is not None:
@@ -257,12 +264,19 @@ def train(args):
         if ep is not None:
             start_epoch = ep
     model = wrap_for_training(model, local_rank)
+    graphed = None
+    if args.graph_train:
+        if world > 1:
+            raise SystemExit("--graph-train captures a single-process iteration; run multi-rank training without it")
+        from .train_graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, device)      # before the schedulers: they then drive the device-side lr
     steps = max(1, args.epochs * len(train_ds) // batch_size // 6 // max(world, 1))
     lr_scheduler = torch.optim.lr_scheduler.CyclicLR(optimizer, base_lr=1e-6, max_lr=1e-3, cycle_momentum=False,
                                                      step_size_up=steps, step_size_down=steps, mode="triangular")
     bnm = BNMomentumScheduler(model, lambda i: max(args.bn_momentum * args.bn_decay ** int(i * batch_size / args.decay_step),
                                                    bnm_clip), last_epoch=it)
-    trainer = Trainer(model, optimizer, log_dir, obj_name, lr_scheduler, bnm, device, local_rank, args.save_every, args.log_every)
+    trainer = Trainer(model, optimizer, log_dir, obj_name, lr_scheduler, bnm, device, local_rank, args.save_every, args.log_every,
+                      graphed_step=graphed)
     trainer.train(start_epoch, args.epochs, loader, sampler, max_iters=args.max_iters)
     return trainer
 
