@@ -33,23 +33,10 @@ constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
 #define GDM_CONV_EXP 0                   // development: 1 = no weight staging / barrier after panel 0, 2 = no operand reloads (wrong results)
 #endif
 
-__device__ __forceinline__ unsigned short bf16_rne(float v)
-{
-    unsigned u = __float_as_uint(v);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-
 __device__ __forceinline__ void split8(const float* v, unsigned (&hi)[4], unsigned (&lo)[4])
 {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned short h0 = bf16_rne(v[2 * j]), h1 = bf16_rne(v[2 * j + 1]);
-        const unsigned short l0 = bf16_rne(v[2 * j] - bf16_f32(h0)), l1 = bf16_rne(v[2 * j + 1] - bf16_f32(h1));
-        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-    }
+    for (int j = 0; j < 4; ++j) gdm_split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
 }
 
 // x f32[B,C,H,W] -> packed activations, PLANAR by 16-byte MFMA fragment: for every (b, 128-channel chunk) 32 planes of the

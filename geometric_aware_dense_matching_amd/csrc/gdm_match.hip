@@ -44,13 +44,6 @@ constexpr int TILE_BYTES = MT_COLS * ROW_BYTES;   // 32 KiB
 // ------------------------------------------------------------------------------------------
 // pack: [R, 128, n] -> R*n rows
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v)
-{
-    unsigned u = __float_as_uint(v);
-    u += 0x7FFFu + ((u >> 16) & 1u);   // finite inputs only (descriptors are finite)
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 template <int PREC>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int n, unsigned char* __restrict__ out)
@@ -87,12 +80,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             unsigned hi[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned short h0 = f32_to_bf16_rne(v[2 * j]);
-                const unsigned short h1 = f32_to_bf16_rne(v[2 * j + 1]);
-                const unsigned short l0 = f32_to_bf16_rne(v[2 * j] - bf16_to_f32(h0));
-                const unsigned short l1 = f32_to_bf16_rne(v[2 * j + 1] - bf16_to_f32(h1));
-                hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-                lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                gdm_split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
             }
             *reinterpret_cast<uint4*>(row + ch * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             *reinterpret_cast<uint4*>(row + 256 + ch * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);

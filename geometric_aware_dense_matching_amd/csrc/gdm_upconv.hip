@@ -8,6 +8,8 @@
 // from there.  z never reaches HBM; the price is the halo (121 / 64 patch pixels per tile).
 #include "gdm_common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -36,12 +38,7 @@ constexpr int UF_ALIAS_OFF = UF_XS;
 #endif
 constexpr int UF_LDS = UF_ALIAS_OFF + UF_R0 + UF_WS;
 
-__device__ __forceinline__ unsigned short bf16_rne(float v)
-{
-    unsigned u = __float_as_uint(v);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short bf16_rne(float v) { return gdm_bf16_1(v); }
 __device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 // 16-byte chunk `ch` (0-7 hi, 8-15 lo) of packed row r, XOR-swizzled so that 16 rows' same chunk hit 16 different bank groups
@@ -205,6 +202,183 @@ __global__ __launch_bounds__(256, 2) void upconv_fused64_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Direct form: the workgroup builds the UPSAMPLED tile (8 x 16 output pixels + the one-pixel ring the 3x3 taps reach, 64 channels,
+// split bf16 hi / lo) in LDS and runs the 3x3 convolution on it: nine taps x K = 64 on the matrix cores with the tap's weights
+// staged through LDS (double-buffered), accumulators in registers, one store per output.  Against the z-gather form above: twice
+// the MFMA work (the product runs at output resolution), but no [9*64, patch] intermediate in LDS and no 36-read gather per
+// output value, which is what bounded that kernel (LDS reads: 2.4 MB per 256 outputs x 64 channels).  The upsampled value is
+// formed exactly as torch's upsample_bilinear2d (align_corners) forms it, then split -- so the result is conv3x3(up(x)) in the
+// reference's own order of operations (models/cnn/pspnet.py:34-45), to split-bf16 accuracy.
+constexpr int UT_TX = 16, UT_TY = 8;                  // output tile
+constexpr int UT_NT = 4;                              // tiles (stacked in y) per workgroup: the next tile's source patch is in flight
+                                                      // during this tile's matrix work, and stores never wait for a workgroup's end
+constexpr int UT_HW = UT_TX + 2;                      // tile row stride with the ring (18)
+constexpr int UT_ROWS = (UT_TY + 2) * UT_HW;          // 180 packed rows
+constexpr int UT_TILE = UT_ROWS * UF_ROWB;            // 46 080 B
+constexpr int UT_WBUF = UF_C * UF_ROWB;               // one tap's weights: 16 KiB
+constexpr int UT_PH = 8, UT_PWV = 11;                 // source patch rows / columns: checked on the host for the scale factors
+constexpr int UT_PW = 16;                             // patch row stride (a thread's patch position is then shifts of its index)
+constexpr int UT_PS = UT_PH * UT_PW;                  // floats per channel of the patch
+constexpr int UT_NE = UF_C * UT_PS / 256;             // patch elements per thread (32: channels t/128 + 2 i at position t % 128)
+constexpr int UT_LDS = UT_TILE + 2 * UT_WBUF + 2 * UF_C * 4;   // 79 360 B: two workgroups per CU
+static_assert(UF_C * UT_PS * 4 <= 2 * UT_WBUF, "the fp32 patch aliases the weight buffers");
+static_assert(UF_C * UT_PS % 256 == 0, "whole patch elements per thread");
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void upconv_tile64_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int H, int W, int OH, int OW, float rh, float rw, float slope,
+                                                             float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    unsigned char* ws = smem + UT_TILE;
+    float* patch = reinterpret_cast<float*>(ws);                 // between two tiles' tap loops only
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int ox_t = blockIdx.x * UT_TX;
+    const float* xb = x + (long)b * UF_C * H * W;
+    const int xs0 = min((int)(rw * (float)max(ox_t - 1, 0)), W - 1);
+    const int xs1 = min((int)(rw * (float)min(ox_t + UT_TX, OW - 1)) + 1, W - 1);
+    const int pw = xs1 - xs0 + 1;                                  // <= UT_PW
+
+    u32x4 stage[4];
+    auto stage_load = [&](int tap) {
+        const unsigned char* src = wpk + (long)tap * UT_WBUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const u32x4*>(src + (long)(i * 256 + tid) * 16);
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char* dst = ws + buf * UT_WBUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = i * 256 + tid;
+            *reinterpret_cast<u32x4*>(dst + uf_off(g >> 4, g & 15)) = stage[i];
+        }
+    };
+    // source window of a tile (ring and the +1 bilinear neighbour included): first row and row count
+    auto window = [&](int oy_t, int& ys0, int& ph) {
+        ys0 = min((int)(rh * (float)max(oy_t - 1, 0)), H - 1);
+        const int ys1 = min((int)(rh * (float)min(oy_t + UT_TY, OH - 1)) + 1, H - 1);
+        ph = ys1 - ys0 + 1;                                        // <= UT_PH
+    };
+    float pv[UT_NE];
+    const int pc = tid & 15, pr = (tid >> 4) & 7;                  // this thread's patch position, channels (tid >> 7) + 2 i
+    auto patch_load = [&](int oy_t) {
+        int ys0, ph;
+        window(oy_t, ys0, ph);
+        const bool ok = pr < ph && pc < pw;
+        const float* src = xb + ((long)(tid >> 7) * H + min(ys0 + pr, H - 1)) * W + min(xs0 + pc, W - 1);
+#pragma unroll
+        for (int i = 0; i < UT_NE; ++i) pv[i] = ok ? src[(long)(2 * i) * H * W] : 0.f;
+    };
+
+    const int prow = 2 * wave + (lr >> 4), pcol = lr & 15;         // the wave's 32 output pixels: two tile rows of 16
+    float* ssc = reinterpret_cast<float*>(smem + UT_TILE + 2 * UT_WBUF);    // scale[64] | shift[64]
+    if (tid < 2 * UF_C) ssc[tid] = tid < UF_C ? scale[tid] : shift[tid - UF_C];
+
+    const int oy_first = blockIdx.y * (UT_NT * UT_TY);
+    patch_load(oy_first);
+    stage_load(0);
+#pragma unroll 1
+    for (int it = 0; it < UT_NT; ++it) {
+        const int oy_t = oy_first + it * UT_TY;
+        if (oy_t >= OH) break;                                     // uniform
+        // ---- A: this tile's source patch registers -> LDS (fp32); then the next tile's loads go out ----
+#pragma unroll
+        for (int i = 0; i < UT_NE; ++i) patch[tid + 256 * i] = pv[i];
+        __syncthreads();
+        int ys0, ph;
+        window(oy_t, ys0, ph);
+        if (it + 1 < UT_NT && oy_t + UT_TY < OH) patch_load(oy_t + UT_TY);
+
+        // ---- B: up(x) on the tile, 8 channels of one tile pixel per item, as torch's upsample_bilinear2d (align_corners) ----
+#pragma unroll 1
+        for (int item = tid; item < 8 * UT_ROWS; item += 256) {
+            const int grp = item / UT_ROWS, px = item - grp * UT_ROWS;
+            const int r = px / UT_HW, c = px - r * UT_HW;
+            const int yy = oy_t - 1 + r, xx = ox_t - 1 + c;
+            unsigned hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+            if (yy >= 0 && yy < OH && xx >= 0 && xx < OW) {        // outside: the convolution's zero padding
+                const float sy = rh * (float)yy, sx = rw * (float)xx;
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int yp = y0 < H - 1 ? UT_PW : 0, xp = x0 < W - 1 ? 1 : 0;
+                const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+                const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const float* p0 = patch + (grp * 8) * UT_PS + (y0 - ys0) * UT_PW + (x0 - xs0);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* p = p0 + j * UT_PS;
+                    v[j] = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[yp] + lx1 * p[yp + xp]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gdm_split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+            }
+            *reinterpret_cast<u32x4*>(tile + uf_off(px, grp)) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(tile + uf_off(px, 8 + grp)) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+        __syncthreads();                                           // tile complete, patch dead
+        stage_store(0);                                            // tap 0's weights (loaded before the loop / during the last tap)
+        __syncthreads();
+
+        // ---- C: nine taps x K = 64 for 32 pixels x 64 output channels per wave ----
+        f32x16 acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            stage_load(tap + 1 < 9 ? tap + 1 : 0);                 // the last tap fetches tap 0 for the next tile
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int R = (prow + ky) * UT_HW + pcol + kx;
+            const unsigned char* wb = ws + (tap & 1) * UT_WBUF;
+            u32x4 bh[4], bl[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bh[s] = *reinterpret_cast<const u32x4*>(tile + uf_off(R, 2 * s + h));
+                bl[s] = *reinterpret_cast<const u32x4*>(tile + uf_off(R, 8 + 2 * s + h));
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int n = cb * 32 + lr;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wb + uf_off(n, 2 * s + h)));
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wb + uf_off(n, 8 + 2 * s + h)));
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[s]);
+                    const bf16x8 xl = __builtin_bit_cast(bf16x8, bl[s]);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[cb], 0, 0, 0);
+                }
+            }
+            if (tap + 1 < 9) stage_store((tap + 1) & 1);           // last read in iteration tap - 1, which ended with a barrier
+            __syncthreads();
+        }
+
+        // ---- D: lane = output pixel, registers = output channels ----
+        const int oy = oy_t + prow, ox = ox_t + pcol;
+        if (oy < OH && ox < OW) {
+            float* ob = out + (((long)b * UF_C) * OH + oy) * OW + ox;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    float o = acc[cb][reg] * ssc[co] + ssc[UF_C + co];
+                    if (ACT == 1) o = fmaxf(o, 0.f);
+                    if (ACT == 2) o = o > 0.f ? o : o * slope;
+                    ob[(long)co * OH * OW] = o;
+                }
+        }
+    }
+}
+
 inline float uf_scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -225,6 +399,30 @@ extern "C" int gdm_upconv_fused64_hip(const float* x, const void* wpk, const flo
     GDM_CHECK_ARG(C == UF_C, "gdm_upconv_fused64_hip: C=%d, built for 64 -> 64 channels", C);
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && OH >= 1 && OW >= 1 && act >= 0 && act <= 2, "gdm_upconv_fused64_hip: bad shape");
     const float rh = uf_scale_ac(H, OH), rw = uf_scale_ac(W, OW);
+    hipStream_t s = (hipStream_t)stream;
+    static int form = -1;                                         // GDM_UPCONV_FUSED64=gather: the z-gather kernel (development A/B)
+    if (form < 0) {
+        const char* e = getenv("GDM_UPCONV_FUSED64");
+        form = (e && !strcmp(e, "gather")) ? 1 : 0;
+    }
+    if (form == 0) {
+        // worst-case source window of a tile edge: (edge + 1) output steps of size r, + the +1 neighbour, + rounding
+        GDM_CHECK_ARG((int)(rh * (UT_TY + 1)) + 3 <= UT_PH && (int)(rw * (UT_TX + 1)) + 3 <= UT_PWV,
+                      "gdm_upconv_fused64_hip: scale factors %g x %g need a source patch larger than %dx%d", rh, rw, UT_PH, UT_PWV);
+        static bool attr_t = false;
+        if (!attr_t) {
+            (void)hipFuncSetAttribute((const void*)upconv_tile64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
+            (void)hipFuncSetAttribute((const void*)upconv_tile64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
+            (void)hipFuncSetAttribute((const void*)upconv_tile64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
+            attr_t = true;
+        }
+        dim3 gt(gdm_cdiv(OW, UT_TX), gdm_cdiv(OH, UT_TY * UT_NT), B);
+        GDM_CHECK_ARG(gt.y <= 65535, "gdm_upconv_fused64_hip: OH=%d too large", OH);
+        if (act == 0) hipLaunchKernelGGL(upconv_tile64_kernel<0>, gt, dim3(256), UT_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
+        else if (act == 1) hipLaunchKernelGGL(upconv_tile64_kernel<1>, gt, dim3(256), UT_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
+        else hipLaunchKernelGGL(upconv_tile64_kernel<2>, gt, dim3(256), UT_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
+        return gdm_launch_status("upconv_tile64_kernel");
+    }
     // worst-case source window of a 16-pixel tile edge: (16 + 1) output steps of size r, + the +1 neighbour, + rounding
     GDM_CHECK_ARG((int)(rh * (UF_T + 1)) + 3 <= UF_PW && (int)(rw * (UF_T + 1)) + 3 <= UF_PW,
                   "gdm_upconv_fused64_hip: scale factors %g x %g need a source patch larger than %dx%d", rh, rw, UF_PW, UF_PW);
@@ -236,7 +434,6 @@ extern "C" int gdm_upconv_fused64_hip(const float* x, const void* wpk, const flo
         attr = true;
     }
     dim3 grid(gdm_cdiv(OW, UF_T), gdm_cdiv(OH, UF_T), B);
-    hipStream_t s = (hipStream_t)stream;
     if (act == 0) hipLaunchKernelGGL(upconv_fused64_kernel<0>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
     else if (act == 1) hipLaunchKernelGGL(upconv_fused64_kernel<1>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
     else hipLaunchKernelGGL(upconv_fused64_kernel<2>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
