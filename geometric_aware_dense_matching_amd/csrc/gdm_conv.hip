@@ -393,20 +393,22 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             alo[S][ph] = *reinterpret_cast<const u32x4*>(r + S * sstride + lostride + pixbase[ph] * 16);
         }
     };
-    u32x4 stage[MF_STAGE];
-    auto stage_load = [&](int it) {
+    // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
+    constexpr int HS = MF_STAGE / 2;
+    u32x4 stage[HS];
+    auto stage_load = [&](int it, int half) {
         const unsigned char* src = wpk + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
-        for (int i = 0; i < MF_STAGE; ++i) {
-            const int g = i * MF_THREADS + tid;
+        for (int i = 0; i < HS; ++i) {
+            const int g = (half * HS + i) * MF_THREADS + tid;
             stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int half) {
         unsigned char* base = smem + buf * CV_PANEL;
 #pragma unroll
-        for (int i = 0; i < MF_STAGE; ++i) {
-            const int g = i * MF_THREADS + tid;
+        for (int i = 0; i < HS; ++i) {
+            const int g = (half * HS + i) * MF_THREADS + tid;
             *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
         }
     };
@@ -420,8 +422,10 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             for (int i = 0; i < 4; ++i) acc[ph][cb][i] = 0.f;
 
     constexpr int LATE = 1;                                         // k-steps whose reload is deferred to the next iteration's top
-    stage_load(0);
-    stage_store(0);
+    stage_load(0, 0);
+    stage_store(0, 0);
+    stage_load(0, 1);
+    stage_store(0, 1);
     {
         const unsigned char* r0 = a_row(0);
 #pragma unroll
@@ -466,8 +470,12 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                 }
             }
             if (pr == 3 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
+            if (u == NU / 2 && more) {                              // the other buffer's readers finished at this panel's barrier
+                stage_store((it + 1) & 1, 0);
+                stage_load(it + 1, 1);
+            }
             if (u == 0) {
-                if (more) stage_load(it + 1);
+                if (more) stage_load(it + 1, 0);
 #pragma unroll
                 for (int S2 = NS - LATE; S2 < NS; ++S2) load_a(rcur, S2);
             }
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stage_store((it + 1) & 1);
+        if (more) stage_store((it + 1) & 1, 1);
     }
 
     // ---- epilogue: lane = output channel 16 cb + l16, registers = 4 consecutive pixels 16 ph + 4 kg + r ----
