@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float*
 // + t[b,co,idx[b,j]]) + shift[co]) for the 64-channel levels (ffb6d.py:216-222 at ds stage 0, :252-258 at up stages 1-2), where
 // the GEMM has K = 64: hipBLASLt's f32 kernel runs it at ~0.5 TB/s (62 us per call) and the intermediate costs a write + a read.
 // One pass, thread = pixel, 64 accumulators in registers, W^T rows as wave-uniform scalar loads; exact fp32 FMAs.
-template <int C, int ACT>
+// PM: y is written pixel-major, f32[B, m, C] (256 contiguous bytes per pixel) -- the layout the sampled-pixel final stage reads.
+template <int C, int ACT, bool PM = false>
 __global__ __launch_bounds__(256) void conv1x1_gather_add_act_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                      const float* __restrict__ t, const int32_t* __restrict__ idx,
                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
@@ -720,13 +721,17 @@ __global__ __launch_bounds__(256) void conv1x1_gather_add_act_kernel(const float
 #pragma unroll
         for (int co = 0; co < C; ++co) acc[co] = fmaf(wt[ci * C + co], xv, acc[co]);
     }
-    float* yb = y + (long)b * C * m + j;
+    float* yb = PM ? y + ((long)b * m + j) * C : y + (long)b * C * m + j;
 #pragma unroll
     for (int co = 0; co < C; ++co) {
         float o = scale[co] * acc[co] + shift[co];
         if (ACT == 1) o = fmaxf(o, 0.f);
         if (ACT == 2) o = o > 0.f ? o : o * slope;
-        yb[(long)co * m] = o;
+        if (PM) acc[co] = o; else yb[(long)co * m] = o;
+    }
+    if (PM) {
+#pragma unroll
+        for (int co = 0; co < C; co += 4) *reinterpret_cast<float4*>(yb + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
     }
 }
 
@@ -1037,18 +1042,26 @@ extern "C" int gdm_gather_add_affine_act_hip(const float* x, const float* t, con
     return gdm_launch_status("gather_add_affine_act_kernel");
 }
 
-extern "C" int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
-                                              const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream)
+extern "C" int gdm_conv1x1_gather_add_act2_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
+                                               const float* shift, int B, int C, int n, long m, int act, float slope, int pixel_major,
+                                               float* y, void* stream)
 {
     GDM_CHECK_ARG(x && wt && t && idx && scale && shift && y, "gdm_conv1x1_gather_add_act_hip: NULL pointer");
     GDM_CHECK_ARG(C == 64, "gdm_conv1x1_gather_add_act_hip: C=%d, only the 64-channel fusion levels are built", C);
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1 && m >= 1 && act >= 0 && act <= 2, "gdm_conv1x1_gather_add_act_hip: bad shape");
     dim3 grid(gdm_cdiv(m, 256), B);
     hipStream_t s = (hipStream_t)stream;
-    if (act == 0) hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 0>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
-    else if (act == 1) hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 1>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
-    else hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, 2>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y);
+#define CGA(A, P) hipLaunchKernelGGL((conv1x1_gather_add_act_kernel<64, A, P>), grid, dim3(256), 0, s, x, wt, t, idx, scale, shift, n, m, slope, y)
+    if (pixel_major) { if (act == 0) CGA(0, true); else if (act == 1) CGA(1, true); else CGA(2, true); }
+    else { if (act == 0) CGA(0, false); else if (act == 1) CGA(1, false); else CGA(2, false); }
+#undef CGA
     return gdm_launch_status("conv1x1_gather_add_act_kernel");
+}
+
+extern "C" int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
+                                              const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream)
+{
+    return gdm_conv1x1_gather_add_act2_hip(x, wt, t, idx, scale, shift, B, C, n, m, act, slope, 0, y, stream);
 }
 
 extern "C" int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream)

@@ -379,6 +379,219 @@ __global__ __launch_bounds__(256, 2) void upconv_tile64_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The last image stage at the SAMPLED pixels only (inference).  FFB6DEmb ends with up_3 = PSPUpsample(64 -> 64) to full resolution,
+// `final` = Conv1x1(64 -> 64) + LogSoftmax, and then keeps the N `choose` pixels of each crop (ffb6d.py:266-285 of the reference:
+// cnn_up_stages[3], torch.gather with choose_emb).  Both modules are per-pixel functions of the 3x3 upsampled neighbourhood, so in
+// eval mode (BatchNorm on running statistics) the values at the chosen pixels are all that is ever read: 2 048 of 65 536 pixels per
+// crop.  One workgroup takes 32 chosen pixels of one crop: for every tap it forms up(x) at the tap position exactly as
+// upsample_bilinear2d (align_corners) does -- from the pixel-major source map, 256 contiguous bytes per source pixel -- splits it to
+// bf16 hi/lo in LDS, accumulates W_tap . up(x) on the matrix cores (weights straight from L2 into the A fragments), applies BN + PReLU,
+// then runs the 64 -> 64 `final` convolution the same way on the result and finishes the log-softmax over the 64 channels
+// (two lane shuffles + one exchange through LDS).  Same products and summation structure as the dense kernels, 1/32 of the work.
+constexpr int FP_P = 32;                              // chosen pixels per workgroup
+constexpr int FP_ABUF = FP_P * UF_ROWB;               // one tap's operand rows: 8 KiB
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+__device__ __forceinline__ int fp_chunk(int row, int ch) { return uf_off(row, ch); }
+
+template <int ACT>
+__global__ __launch_bounds__(256, 4) void upconv_final_points_kernel(const float* __restrict__ xpm, const int32_t* __restrict__ choose,
+                                                                   const unsigned char* __restrict__ wpk, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const unsigned char* __restrict__ wfpk,
+                                                                   const float* __restrict__ fbias, int H, int W, int OH, int OW, int N,
+                                                                   float rh, float rw, float slope, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char abuf[2 * FP_ABUF];
+    __shared__ float red[2][4][FP_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y, n0 = blockIdx.x * FP_P;
+
+    // ---- builder role: thread = (chosen pixel tid >> 3, 8-channel group tid & 7) ----
+    const int bp = tid >> 3, grp = tid & 7;
+    int oy, ox;
+    {
+        int ch = choose[(long)b * N + min(n0 + bp, N - 1)];
+        ch = min(max(ch, 0), OH * OW - 1);
+        oy = ch / OW;
+        ox = ch - oy * OW;
+    }
+    const float* xb = xpm + (long)b * H * W * UF_C + grp * 8;
+    f32x4v raw[8];                                              // 4 corners x 8 channels of the tap being built
+    float ly1, lx1;
+    bool inside;
+    auto corners_load = [&](int tap) {
+        const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+        inside = yy >= 0 && yy < OH && xx >= 0 && xx < OW;       // outside: the convolution's zero padding
+        const float sy = rh * (float)min(max(yy, 0), OH - 1), sx = rw * (float)min(max(xx, 0), OW - 1);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+        ly1 = sy - (float)y0;
+        lx1 = sx - (float)x0;
+        const float* p00 = xb + ((long)y0 * W + x0) * UF_C;
+        const float* p01 = p00 + xp * UF_C;
+        const float* p10 = p00 + (long)yp * W * UF_C;
+        const float* p11 = p10 + xp * UF_C;
+        raw[0] = *reinterpret_cast<const f32x4v*>(p00);
+        raw[1] = *reinterpret_cast<const f32x4v*>(p00 + 4);
+        raw[2] = *reinterpret_cast<const f32x4v*>(p01);
+        raw[3] = *reinterpret_cast<const f32x4v*>(p01 + 4);
+        raw[4] = *reinterpret_cast<const f32x4v*>(p10);
+        raw[5] = *reinterpret_cast<const f32x4v*>(p10 + 4);
+        raw[6] = *reinterpret_cast<const f32x4v*>(p11);
+        raw[7] = *reinterpret_cast<const f32x4v*>(p11 + 4);
+    };
+    auto rows_store = [&](int buf) {                              // up(x) as upsample_bilinear2d forms it, split, one 16-B chunk hi + lo
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = 2 * j + e;
+                const float a = raw[c >> 2][c & 3], bq = raw[2 + (c >> 2)][c & 3], cq = raw[4 + (c >> 2)][c & 3], d = raw[6 + (c >> 2)][c & 3];
+                v[e] = inside ? ly0 * (lx0 * a + lx1 * bq) + ly1 * (lx0 * cq + lx1 * d) : 0.f;
+            }
+            gdm_split2(v[0], v[1], hi[j], lo[j]);
+        }
+        unsigned char* dst = abuf + buf * FP_ABUF;
+        *reinterpret_cast<u32x4*>(dst + fp_chunk(bp, grp)) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(dst + fp_chunk(bp, 8 + grp)) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+
+    // ---- matrix role: wave = 16 output channels x the 32 pixels (two 16-column blocks), 16x16x32 products ----
+    // A fragment (weights): lane (row l16 = channel 16 wave + l16, k-group kg): 8 input channels 32 S + 8 kg .. of k-step S
+    u32x4 wh[2], wl[2];
+    auto weights_load = [&](const unsigned char* rows) {           // rows: 64 packed rows of 256 B (64 bf16 hi | 64 bf16 lo)
+        const unsigned char* r = rows + (long)(16 * wave + l16) * UF_ROWB;
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            wh[S] = *reinterpret_cast<const u32x4*>(r + (4 * S + kg) * 16);
+            wl[S] = *reinterpret_cast<const u32x4*>(r + (8 + 4 * S + kg) * 16);
+        }
+    };
+    f32x4v acc[2];
+    auto mma = [&](int buf) {
+        const unsigned char* src = abuf + buf * FP_ABUF;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + fp_chunk(16 * pb + l16, 4 * S + kg)));
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + fp_chunk(16 * pb + l16, 8 + 4 * S + kg)));
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[S]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[S]);
+                acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc[pb], 0, 0, 0);
+                acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc[pb], 0, 0, 0);
+                acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc[pb], 0, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) acc[pb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    corners_load(0);
+    rows_store(0);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        weights_load(wpk + (long)tap * UF_C * UF_ROWB);
+        if (tap + 1 < 9) corners_load(tap + 1);                    // in flight during this tap's products
+        __syncthreads();                                           // buffer tap & 1 is complete; the other one's readers are done
+        mma(tap & 1);
+        if (tap + 1 < 9) rows_store((tap + 1) & 1);
+    }
+    weights_load(wfpk);                                            // `final`'s weights, in flight during the epilogue
+    __syncthreads();                                               // all products of tap 8 are done with buffer 0
+
+    // ---- BN (+ conv bias) + PReLU; the result becomes the operand rows of `final` (buffer 0) ----
+    // accumulator: lane column l16 = pixel 16 pb + l16, registers r = output channels 16 wave + 4 kg + r
+    {
+        const int c0 = 16 * wave + 4 * kg;
+        const f32x4v sc = f32x4v{scale[c0], scale[c0 + 1], scale[c0 + 2], scale[c0 + 3]};
+        const f32x4v sh = f32x4v{shift[c0], shift[c0 + 1], shift[c0 + 2], shift[c0 + 3]};
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = acc[pb][r] * sc[r] + sh[r];
+                if (ACT == 1) o = fmaxf(o, 0.f);
+                if (ACT == 2) o = o > 0.f ? o : o * slope;
+                v[r] = o;
+            }
+            unsigned h0, l0, h1, l1;
+            gdm_split2(v[0], v[1], h0, l0);
+            gdm_split2(v[2], v[3], h1, l1);
+            // channels c0 .. c0+3: chunk c0 / 8 = 2 wave + (kg >> 1), bytes 8 (kg & 1) .. of the chunk
+            unsigned char* row = abuf + fp_chunk(16 * pb + l16, 2 * wave + (kg >> 1)) + 8 * (kg & 1);
+            *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+            unsigned char* rowl = abuf + fp_chunk(16 * pb + l16, 8 + 2 * wave + (kg >> 1)) + 8 * (kg & 1);
+            *reinterpret_cast<uint2*>(rowl) = make_uint2(l0, l1);
+            acc[pb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    mma(0);                                                        // `final`: 64 -> 64 on the same pixels
+
+    // ---- + bias, log-softmax over the 64 channels of a pixel: 4 registers x 4 k-groups (lanes l16 + 16 kg) x 4 waves ----
+    {
+        const int c0 = 16 * wave + 4 * kg;
+        f32x4v bq = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (fbias) bq = f32x4v{fbias[c0], fbias[c0 + 1], fbias[c0 + 2], fbias[c0 + 3]};
+        float y[2][4], m[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[pb][r] = acc[pb][r] + bq[r];
+            m[pb] = fmaxf(fmaxf(y[pb][0], y[pb][1]), fmaxf(y[pb][2], y[pb][3]));
+            m[pb] = fmaxf(m[pb], __shfl_xor(m[pb], 16));
+            m[pb] = fmaxf(m[pb], __shfl_xor(m[pb], 32));
+            if (kg == 0) red[0][wave][16 * pb + l16] = m[pb];
+        }
+        __syncthreads();
+        float ssum[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int p = 16 * pb + l16;
+            m[pb] = fmaxf(fmaxf(red[0][0][p], red[0][1][p]), fmaxf(red[0][2][p], red[0][3][p]));
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += expf(y[pb][r] - m[pb]);
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (kg == 0) red[1][wave][p] = q;
+            ssum[pb] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int p = 16 * pb + l16;
+            const float tot = (red[1][0][p] + red[1][1][p]) + (red[1][2][p] + red[1][3][p]);
+            const float lse = m[pb] + logf(tot);
+            if (n0 + p < N) {
+                float* ob = out + ((long)b * UF_C + c0) * N + n0 + p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[(long)r * N] = y[pb][r] - lse;
+            }
+        }
+        (void)ssum;
+    }
+}
+
+// w f32[R, 64] -> R rows of 256 B: 64 bf16 hi | 64 bf16 lo
+__global__ __launch_bounds__(256) void pack_rows64_kernel(const float* __restrict__ w, int R, unsigned char* __restrict__ out)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;           // (row, pair of channels)
+    if (item >= R * 32) return;
+    const int row = item >> 5, c = (item & 31) * 2;
+    unsigned hi, lo;
+    gdm_split2(w[(long)row * UF_C + c], w[(long)row * UF_C + c + 1], hi, lo);
+    unsigned* r = reinterpret_cast<unsigned*>(out + (long)row * UF_ROWB);
+    r[c >> 1] = hi;
+    r[32 + (c >> 1)] = lo;
+}
+
 inline float uf_scale_ac(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 } // namespace
@@ -438,4 +651,27 @@ extern "C" int gdm_upconv_fused64_hip(const float* x, const void* wpk, const flo
     else if (act == 1) hipLaunchKernelGGL(upconv_fused64_kernel<1>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
     else hipLaunchKernelGGL(upconv_fused64_kernel<2>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
     return gdm_launch_status("upconv_fused64_kernel");
+}
+
+extern "C" int gdm_pack_rows64_hip(const float* w, int R, void* out, void* stream)
+{
+    GDM_CHECK_ARG(w && out && R >= 1, "gdm_pack_rows64_hip: bad arguments");
+    hipLaunchKernelGGL(pack_rows64_kernel, dim3(gdm_cdiv((long)R * 32, 256)), dim3(256), 0, (hipStream_t)stream, w, R, (unsigned char*)out);
+    return gdm_launch_status("pack_rows64_kernel");
+}
+
+extern "C" int gdm_upconv_final_points_hip(const float* xpm, const int32_t* choose, const void* wpk, const float* scale, const float* shift,
+                                           int act, float slope, const void* wfpk, const float* fbias, int B, int H, int W, int OH, int OW,
+                                           int N, float* out, void* stream)
+{
+    GDM_CHECK_ARG(xpm && choose && wpk && scale && shift && wfpk && out, "gdm_upconv_final_points_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && OH >= 1 && OW >= 1 && N >= 1 && act >= 0 && act <= 2 &&
+                  (long)OH * OW <= 0x7fffffffL, "gdm_upconv_final_points_hip: bad shape");
+    const float rh = uf_scale_ac(H, OH), rw = uf_scale_ac(W, OW);
+    dim3 grid(gdm_cdiv(N, FP_P), B);
+    hipStream_t s = (hipStream_t)stream;
+#define FPK(A) hipLaunchKernelGGL(upconv_final_points_kernel<A>, grid, dim3(256), 0, s, xpm, choose, (const unsigned char*)wpk, scale, shift, (const unsigned char*)wfpk, fbias, H, W, OH, OW, N, rh, rw, slope, out)
+    if (act == 0) FPK(0); else if (act == 1) FPK(1); else FPK(2);
+#undef FPK
+    return gdm_launch_status("upconv_final_points_kernel");
 }

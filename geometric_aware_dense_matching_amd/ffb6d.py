@@ -119,7 +119,7 @@ class FFB6DEmb(nn.Module):
             layer.__dict__["_gdm_wa_t"] = cache
         return cache[1]
 
-    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx):
+    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False):
         """fuse(cat(rgb_emb0, nearest_interp(pre(p_emb0)))) (ffb6d.py:216-222,252-258).  Eval: the point half of the
         1x1 fuse convolution runs at the points (a 1x1 conv commutes with the gather), the pixel half is a GEMM with half
         the K, and gather + add + BN + ReLU is one HIP launch; no concat, no full-resolution point features."""
@@ -133,8 +133,10 @@ class FFB6DEmb(nn.Module):
                     # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
                     y = ops.conv1x1_gather_add_act(rgb_emb0.reshape(bs, c, hr * wr), self._fuse_weight_t(fuse_layer, wa), t,
-                                                   idx.reshape(bs, -1), scale, shift, code[0], code[1])
-                    return y.view(bs, -1, hr, wr)
+                                                   idx.reshape(bs, -1), scale, shift, code[0], code[1], pixel_major=pixel_major)
+                    return y if pixel_major else y.view(bs, -1, hr, wr)  # pixel-major: [B, H*W, 64] for _final_at_choose
+                if pixel_major:
+                    raise RuntimeError("pixel-major fusion output is the 64-channel kernel's; _sparse_final_ok() guards the caller")
                 if settings.USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
                     wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
                     x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA
@@ -143,6 +145,8 @@ class FFB6DEmb(nn.Module):
                 scale, shift = folded_bn(fuse_layer.normlayer.bn)
                 y = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1])
                 return y.view(bs, -1, hr, wr)
+        if pixel_major:
+            raise RuntimeError("pixel-major fusion output is the eval kernel's; _sparse_final_ok() guards the caller")
         p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)
         return fuse_layer(torch.cat((rgb_emb0, p2r_emb), dim=1))
 
@@ -189,6 +193,7 @@ class FFB6DEmb(nn.Module):
             ds_emb.append(p_emb)
 
         n_up = len(self.rndla_up_stages)
+        sparse_final = self._sparse_final_ok(inputs["rgb"])
         for i_up in range(n_up - 1):
             rgb_emb0 = self.cnn_up_stages[i_up](rgb_emb)
             bs, c, hr, wr = rgb_emb0.size()
@@ -197,16 +202,51 @@ class FFB6DEmb(nn.Module):
             p_emb0 = self.rndla_up_stages[i_up](torch.cat([ds_emb[-i_up - 2], f_interp_i], dim=1))
 
             rgb_emb = self._p2r_fuse(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], rgb_emb0, p_emb0,
-                                     inputs["p2r_up_nei_idx%d" % i_up])
+                                     inputs["p2r_up_nei_idx%d" % i_up], pixel_major=sparse_final and i_up == n_up - 2)
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_up_nei_idx%d" % i_up])
             r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)
             p_emb = self.up_fuse_r2p_fuse_layers[i_up](torch.cat((p_emb0, r2p_emb), dim=1))
 
-        rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
         f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx0"])
         p_emb = self.rndla_up_stages[n_up - 1](torch.cat([ds_emb[0], f_interp_i], dim=1)).squeeze(-1)
-
-        bs, di, _, _ = rgb_emb.size()
-        rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+        if sparse_final:
+            # the last stage (up_3 + final) is a per-pixel function of a 3x3 neighbourhood and only the N `choose` pixels of its
+            # full-resolution output are kept (reference ffb6d.py:266-285): evaluate it there, on the pixel-major fused map
+            rgb_emb_c = self._final_at_choose(rgb_emb, (hr, wr), inputs["choose"])
+        else:
+            rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
+            bs, di, _, _ = rgb_emb.size()
+            rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
         return torch.cat([rgb_emb_c, p_emb], dim=1)
+
+    def _sparse_final_ok(self, rgb):
+        """Inference with folded BatchNorm, the last stage = PSPUpsample(64 -> 64) + FinalStage(64 -> 64) and the last fusion on the
+        64-channel kernel: then the stage runs at the chosen pixels only."""
+        from .cnn import FinalStage, PSPUpsample
+        last = self.cnn_up_stages[len(self.rndla_up_stages) - 1]
+        if not (settings.USE_SPARSE_FINAL and settings.USE_FUSED_UPCONV and fused_eval(rgb, self) and len(last) == 2):
+            return False
+        up, fin = last[0], last[1]
+        if not (isinstance(up, PSPUpsample) and isinstance(fin, FinalStage)):
+            return False
+        conv, fconv = up.conv[1], fin[0]
+        fuse = self.up_fuse_p2r_fuse_layers[len(self.rndla_up_stages) - 2]
+        return (conv.in_channels == 64 and conv.out_channels == 64 and fconv.in_channels == 64 and fconv.out_channels == 64
+                and act_code(up.conv[3]) is not None and act_code(getattr(fuse, "activation", None)) is not None
+                and fuse.conv.weight.shape[0] == 64 and fuse.conv.weight.shape[1] == 128 and rgb.shape[0] <= 65535)
+
+    def _final_at_choose(self, x_pm, hw, choose):
+        from .layers import folded_bn as _fbn
+        last = self.cnn_up_stages[len(self.rndla_up_stages) - 1]
+        up, fin = last[0], last[1]
+        conv, fconv = up.conv[1], fin[0]
+        key = (conv.weight._version, conv.weight.data_ptr(), fconv.weight._version, fconv.weight.data_ptr())
+        cache = self.__dict__.get("_gdm_final_pk")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.upconv_fused64_pack_weight(conv.weight), ops.pack_rows64(fconv.weight.reshape(64, 64)))
+            self.__dict__["_gdm_final_pk"] = cache
+        scale, shift = _fbn(up.conv[2], conv.bias)
+        code = act_code(up.conv[3])
+        return ops.upconv_final_points(x_pm, hw, choose, cache[1], scale, shift, code[0], code[1], cache[2], fconv.bias,
+                                       (hw[0] * 2, hw[1] * 2))

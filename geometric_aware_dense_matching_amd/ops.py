@@ -762,9 +762,10 @@ def lfa_supported(d_out, K):
     return K == 16 and d_out in (32, 64, 128, 256)
 
 
-def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
+def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0, pixel_major=False):
     """y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]) in one pass for the 64-channel fusion
-    levels.  x f32[B,64,m], wt f32[64,64] = W transposed (contiguous), t f32[B,64,n], idx int[B,m(,1)].  Inference only."""
+    levels.  x f32[B,64,m], wt f32[64,64] = W transposed (contiguous), t f32[B,64,n], idx int[B,m(,1)].  Inference only.
+    pixel_major: y comes back as f32[B,m,64] (a 256-byte row per pixel: what upconv_final_points reads)."""
     x = _dev(x, torch.float32, "x")
     t = _dev(t, torch.float32, "t")
     wt = _dev(wt, torch.float32, "wt")
@@ -772,11 +773,41 @@ def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0)
     B, C, m = x.shape
     if C != 64 or tuple(wt.shape) != (64, 64) or t.shape[1] != 64:
         raise ValueError("conv1x1_gather_add_act: built for 64 -> 64 channels, got x %s wt %s t %s" % (tuple(x.shape), tuple(wt.shape), tuple(t.shape)))
-    y = torch.empty_like(x)
-    check(_lib.lib().gdm_conv1x1_gather_add_act_hip(x.data_ptr(), wt.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
-                                                    shift.data_ptr(), B, C, t.shape[2], m, act, float(slope), y.data_ptr(), _stream()),
-          "gdm_conv1x1_gather_add_act_hip")
+    y = torch.empty((B, m, C), dtype=torch.float32, device=x.device) if pixel_major else torch.empty_like(x)
+    check(_lib.lib().gdm_conv1x1_gather_add_act2_hip(x.data_ptr(), wt.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
+                                                     shift.data_ptr(), B, C, t.shape[2], m, act, float(slope), int(bool(pixel_major)),
+                                                     y.data_ptr(), _stream()), "gdm_conv1x1_gather_add_act_hip")
     return y
+
+
+def pack_rows64(w2d):
+    """f32[R,64] -> R packed split-bf16 rows of 256 B (64 bf16 hi | 64 bf16 lo), u8 tensor."""
+    w = _dev(w2d.detach(), torch.float32, "w")
+    if w.dim() != 2 or w.shape[1] != 64:
+        raise ValueError("pack_rows64: expected [R,64], got %s" % (tuple(w.shape),))
+    out = torch.empty(w.shape[0] * 256, dtype=torch.uint8, device=w.device)
+    check(_lib.lib().gdm_pack_rows64_hip(w.data_ptr(), w.shape[0], out.data_ptr(), _stream()), "gdm_pack_rows64_hip")
+    return out
+
+
+def upconv_final_points(x_pm, hw, choose, wpk, scale, shift, act, slope, wf_pk, fbias, out_size):
+    """The last image stage at the sampled pixels (inference): log_softmax(Wf . act(scale * conv3x3(up(x)) + shift) + fbias) at pixel
+    choose[b,n] of the out_size map -> f32[B,64,N].  x_pm f32[B,H*W,64] pixel-major, hw = (H, W); wpk from
+    upconv_fused64_pack_weight, wf_pk from pack_rows64(final_weight[64,64])."""
+    x_pm = _dev(x_pm, torch.float32, "x_pm")
+    choose = _idx32(choose, "choose")
+    B = x_pm.shape[0]
+    H, W = int(hw[0]), int(hw[1])
+    if tuple(x_pm.shape) != (B, H * W, 64):
+        raise ValueError("upconv_final_points: x_pm must be [B,H*W,64] with (H, W) = %s, got %s" % ((H, W), tuple(x_pm.shape)))
+    choose = choose.reshape(B, -1)
+    N = choose.shape[1]
+    OH, OW = int(out_size[0]), int(out_size[1])
+    out = torch.empty((B, 64, N), dtype=torch.float32, device=x_pm.device)
+    check(_lib.lib().gdm_upconv_final_points_hip(x_pm.data_ptr(), choose.data_ptr(), wpk.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                 act, float(slope), wf_pk.data_ptr(), fbias.data_ptr() if fbias is not None else None,
+                                                 B, H, W, OH, OW, N, out.data_ptr(), _stream()), "gdm_upconv_final_points_hip")
+    return out
 
 
 _final_wt_cache = {}

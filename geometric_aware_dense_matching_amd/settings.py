@@ -18,6 +18,8 @@ the initial values.
     USE_SIDE_STREAMS           GDM_SIDE_STREAMS           everything on the caller's stream (inference otherwise forks the mesh branch, the
                                                           neighbour pyramid and the point branch of each encoder stage onto side streams)
     UPCONV_MIN_CIN             GDM_UPCONV_MIN_CIN         (int) smallest Cin for the low-resolution form of conv3x3(upsample(x))
+    USE_SPARSE_FINAL           GDM_SPARSE_FINAL           the last image stage (up_3 + final) on the full 2x map, then the gather with `choose`
+                                                          (default: evaluated at the chosen pixels only -- inference, 1/32 of the pixels)
     STATIC_MATCH_ROWS          GDM_STATIC_MATCH_ROWS=1    (default off) matching loss over all B*N rows with zero weight on the unselected
                                                           ones instead of compacting them: no host read; always on under graph capture
 """
@@ -40,10 +42,11 @@ USE_FUSED_BN_TRAIN = _flag("GDM_FUSED_BN_TRAIN")
 USE_FUSED_SYNCBN = _flag("GDM_FUSED_SYNCBN")
 USE_FUSED_MATCH_LOSS = _flag("GDM_FUSED_MATCH_LOSS")
 USE_SIDE_STREAMS = _flag("GDM_SIDE_STREAMS")
+USE_SPARSE_FINAL = _flag("GDM_SPARSE_FINAL")
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
-                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS")
+                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL")

@@ -339,6 +339,10 @@ int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t*
  * y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]); wt f32[C,C] = W transposed ([ci][co]). */
 int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
                                    const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream);
+/* The same with the output layout selectable: pixel_major != 0 writes y f32[B, m, C] (one 256-byte row per pixel). */
+int gdm_conv1x1_gather_add_act2_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
+                                    const float* shift, int B, int C, int n, long m, int act, float slope, int pixel_major,
+                                    float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate),
@@ -361,6 +365,15 @@ int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const float* scale
 
 /* `final` stage of the image branch (pspnet.py:108-112): out = log_softmax_c(W x + b), x,out f32[B,64,hw], W f32[64,64]. */
 int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream);
+/* The last image stage of FFB6DEmb at the SAMPLED pixels only (inference; /root/reference/models/ffb6d.py:266-285: cnn_up_stages[3] =
+ * PSPUpsample(64 -> 64) + `final`, then torch.gather with `choose`): out f32[B,64,N] = log_softmax(Wf . act(scale * conv3x3(up(x)) +
+ * shift) + fbias) at pixel choose[b,n] of the OHxOW map.  xpm f32[B, H*W, 64] is the source map PIXEL-major (written by
+ * gdm_conv1x1_gather_add_act2_hip(pixel_major = 1)); wpk = gdm_upconv_fused64_pack_weight_hip's rows; wfpk = the 64x64 `final` weight
+ * packed by gdm_pack_rows64_hip (R rows of 64 floats -> 256-byte split-bf16 rows); fbias may be NULL.  choose is clamped to the map. */
+int gdm_pack_rows64_hip(const float* w, int R, void* out, void* stream);
+int gdm_upconv_final_points_hip(const float* xpm, const int32_t* choose, const void* wpk, const float* scale, const float* shift,
+                                int act, float slope, const void* wfpk, const float* fbias, int B, int H, int W, int OH, int OW,
+                                int N, float* out, void* stream);
 /* The four adaptive average pools (1,2,3,6 bins) of the pyramid pooling module (pspnet.py:17-20) in one pass:
  * x f32[planes,H,W] -> o1 f32[planes,1], o2 [planes,4], o3 [planes,9], o6 [planes,36] (PyTorch bin edges). */
 int gdm_psp_pools_hip(const float* x, long planes, int H, int W, float* o1, float* o2, float* o3, float* o6, void* stream);

@@ -509,6 +509,44 @@ def test_conv1x1_gather_add_act(ops, act):
         ref = torch.where(ref > 0, ref, ref * 0.2)
     got = ops.conv1x1_gather_add_act(x.cuda(), w.t().contiguous().cuda(), t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2).cpu()
     assert (got.double() - ref).abs().max().item() < 2e-5
+    got_pm = ops.conv1x1_gather_add_act(x.cuda(), w.t().contiguous().cuda(), t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2,
+                                        pixel_major=True).cpu()
+    assert got_pm.shape == (B, m, C) and torch.equal(got_pm.transpose(1, 2), got)          # same arithmetic, other layout
+
+
+@pytest.mark.parametrize("B,H,W,N", [(2, 16, 24, 100), (1, 128, 128, 2048), (3, 9, 7, 33)])
+def test_upconv_final_points_equals_dense_stage_at_the_chosen_pixels(ops, B, H, W, N):
+    """The last image stage (PSPUpsample(64 -> 64) + Conv1x1 + LogSoftmax, /root/reference/models/cnn/pspnet.py:34-45,108-112) evaluated at
+    the `choose` pixels only == the stage on the whole 2x map in torch fp64, gathered (ffb6d.py:266-285).  Chosen pixels include all
+    four corners and the borders (zero padding of the 3x3, clamped bilinear neighbours), duplicates, and a ragged last block."""
+    rs = np.random.RandomState(B * 1000 + N)
+    OH, OW = 2 * H, 2 * W
+    x = torch.from_numpy(rs.randn(B, 64, H, W).astype(np.float32))
+    w3 = torch.from_numpy((rs.randn(64, 64, 3, 3) * 0.05).astype(np.float32))
+    scale = torch.from_numpy(rs.rand(64).astype(np.float32) + 0.5)
+    shift = torch.from_numpy(rs.randn(64).astype(np.float32))
+    wf = torch.from_numpy((rs.randn(64, 64) / 8).astype(np.float32))
+    bf = torch.from_numpy(rs.randn(64).astype(np.float32))
+    choose = rs.randint(0, OH * OW, size=(B, N)).astype(np.int32)
+    choose[:, :6] = [0, OW - 1, (OH - 1) * OW, OH * OW - 1, OW // 2, (OH - 1) * OW + 3]
+    choose[:, 6] = choose[:, 7]
+    up = torch.nn.functional.interpolate(x.double(), size=(OH, OW), mode="bilinear", align_corners=True)
+    h = torch.nn.functional.conv2d(up, w3.double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    h = torch.where(h > 0, h, 0.25 * h)
+    y = torch.einsum("oc,bchw->bohw", wf.double(), h) + bf.double()[None, :, None, None]
+    ref = torch.log_softmax(y, dim=1).reshape(B, 64, -1)
+    ref = torch.gather(ref, 2, torch.from_numpy(choose).long()[:, None, :].expand(B, 64, N))
+    x_pm = x.reshape(B, 64, H * W).transpose(1, 2).contiguous().cuda()
+    got = ops.upconv_final_points(x_pm, (H, W), torch.from_numpy(choose).cuda(), ops.upconv_fused64_pack_weight(w3.cuda()), scale.cuda(),
+                                  shift.cuda(), 2, 0.25, ops.pack_rows64(wf.cuda()), bf.cuda(), (OH, OW)).cpu()
+    assert got.shape == (B, 64, N)
+    assert (got.double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+    got_nobias = ops.upconv_final_points(x_pm, (H, W), torch.from_numpy(choose).cuda(), ops.upconv_fused64_pack_weight(w3.cuda()),
+                                         scale.cuda(), shift.cuda(), 1, 0.0, ops.pack_rows64(wf.cuda()), None, (OH, OW)).cpu()
+    ref1 = torch.log_softmax(torch.einsum("oc,bchw->bohw", wf.double(), torch.nn.functional.conv2d(up, w3.double(), padding=1).mul(
+        scale.double()[None, :, None, None]).add(shift.double()[None, :, None, None]).clamp(min=0)), dim=1).reshape(B, 64, -1)
+    ref1 = torch.gather(ref1, 2, torch.from_numpy(choose).long()[:, None, :].expand(B, 64, N))
+    assert (got_nobias.double() - ref1).abs().max().item() < 5e-5 * max(1.0, ref1.abs().max().item())
 
 
 @pytest.mark.parametrize("d_out,n", [(32, 100), (64, 257), (128, 64), (256, 33)])
