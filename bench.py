@@ -215,8 +215,9 @@ def extra_legs(torch, dev, args, model, N, M):
 
     # ---- strict fp32: f32-MFMA matching, trunk convolutions / GEMMs back on MIOpen / hipBLASLt (no split-bf16 anywhere), eager
     if not args.exact_f32:
-        saved = (settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM)
-        settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM = False, False
+        saved = tuple(getattr(settings, n) for n in settings.SPLIT_BF16_SWITCHES)
+        for n in settings.SPLIT_BF16_SWITCHES:
+            setattr(settings, n, False)
         try:
             d = dev_batch(301, args.batch)
 
@@ -232,7 +233,8 @@ def extra_legs(torch, dev, args, model, N, M):
             out["exact_f32"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager",
                                 "batch": args.batch}
         finally:
-            settings.USE_MFMA_CONV, settings.USE_MFMA_GEMM = saved
+            for n, v in zip(settings.SPLIT_BF16_SWITCHES, saved):
+                setattr(settings, n, v)
 
     # ---- geoMatch_DGCNN variant: eval forward + matching at the same shape
     from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
@@ -300,8 +302,8 @@ def extra_legs(torch, dev, args, model, N, M):
 def main():
     args = parse()
     if args.exact_f32:                      # read by the package at import time
-        os.environ["GDM_MFMA_CONV"] = "0"
-        os.environ["GDM_MFMA_GEMM"] = "0"
+        for env in ("GDM_MFMA_CONV", "GDM_MFMA_GEMM", "GDM_FUSED_UPCONV", "GDM_SPARSE_FINAL", "GDM_FUSED_HEADS"):
+            os.environ[env] = "0"              # every split-bf16 product path off (settings.SPLIT_BF16_SWITCHES)
         args.precision = "f32"
     import numpy as np
     import torch

@@ -136,6 +136,46 @@ class GeoMatch(nn.Module):
         self._mesh_cache = None
         return self.model_emb()
 
+    def _fused_heads(self, rgb):
+        """Packed weights + folded BatchNorms of the per-point heads for ops.point_heads, or None when the fused kernel does not apply
+        (training / autograd, a non-default head structure, split-bf16 GEMMs switched off).  Cached until a parameter changes."""
+        from .layers import act_code, fused_eval, folded_bn, _PtConv
+        if not (settings.USE_FUSED_HEADS and settings.USE_MFMA_GEMM and fused_eval(rgb, self)):
+            return None
+        chain = list(self.feature_encoding_layer) + [self.normalize_feature_layer] + list(self.seg_layer)
+        if len(chain) != 9 or not all(isinstance(m, _PtConv) and isinstance(m.conv, nn.Conv1d) for m in chain):
+            return None
+        deps = []
+        for m in chain:
+            deps += [m.conv.weight] + ([m.conv.bias] if m.conv.bias is not None else [])
+            if hasattr(m, "normlayer"):
+                bn = m.normlayer.bn
+                deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t._version, t.data_ptr()) for t in deps)
+        cache = self.__dict__.get("_gdm_heads")
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        hidden, last = chain[:-1], chain[-1]
+        ok = (all(m.conv.in_channels == 128 and m.conv.out_channels == 128 for m in hidden) and last.conv.in_channels == 128
+              and last.conv.out_channels <= 16 and not hasattr(last, "normlayer") and getattr(last, "activation", None) is None)
+        codes = [act_code(getattr(m, "activation", None)) for m in hidden]
+        ok = ok and all(c is not None and c[0] in (ops.ACT_NONE, ops.ACT_RELU) for c in codes)
+        value = None
+        if ok:
+            with torch.no_grad():
+                layers = []
+                for m, c in zip(hidden, codes):
+                    if hasattr(m, "normlayer"):
+                        scale, shift = folded_bn(m.normlayer.bn, m.conv.bias)
+                    else:
+                        scale, shift = None, (m.conv.bias.detach().contiguous() if m.conv.bias is not None else None)
+                    layers.append((ops.gemm_pack_weight(m.conv.weight.reshape(128, 128)), scale, shift, c[0]))
+                cl = last.conv.out_channels
+                value = (layers, (ops.gemm_pack_weight(last.conv.weight.reshape(cl, 128)),
+                                  last.conv.bias.detach().contiguous() if last.conv.bias is not None else None, cl))
+        self.__dict__["_gdm_heads"] = (key, value)
+        return value
+
     def forward(self, inputs, end_points=None):
         if not end_points:
             end_points = {}
@@ -149,10 +189,15 @@ class GeoMatch(nn.Module):
         else:
             rgbd_emb = self.pcd_emb(inputs)
             mesh_features = self.mesh_features()
-        rgbd_features = self.feature_encoding_layer(rgbd_emb)
-        rgbd_normalized = self.normalize_feature_layer(rgbd_features)
-        rgbd_emb = rgbd_emb + rgbd_normalized
-        seg_features = self.seg_layer(rgbd_emb)
+        heads = self._fused_heads(rgb)
+        if heads is not None:
+            # feature_encoding_layer, normalize_feature_layer, the residual add and seg_layer: nine per-point 1x1 convolutions, one launch
+            rgbd_features, seg_features = ops.point_heads(rgbd_emb, None, heads[0], heads[1], feat_layer=3, res_layer=4)
+        else:
+            rgbd_features = self.feature_encoding_layer(rgbd_emb)
+            rgbd_normalized = self.normalize_feature_layer(rgbd_features)
+            rgbd_emb = rgbd_emb + rgbd_normalized
+            seg_features = self.seg_layer(rgbd_emb)
         mesh_features = mesh_features.unsqueeze(0)
 
         if self.training:

@@ -780,6 +780,37 @@ def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0,
     return y
 
 
+def point_heads(a, b, layers, last, feat_layer, res_layer):
+    """The per-point 1x1-convolution chain of GeoMatch.forward in one launch (inference).  a f32[B,Ca,N] (+ b f32[B,128-Ca,N] or None);
+    layers = [(wpk, scale|None, shift|None, act)] of 128 -> 128 layers (wpk from gemm_pack_weight, act ACT_NONE / ACT_RELU);
+    last = (wpk, bias|None, c_last).  -> (out_feat f32[B,128,N] = affine output of layer feat_layer, out_last f32[B,c_last,N])."""
+    import ctypes
+    a = _dev(a, torch.float32, "a")
+    B, Ca, N = a.shape
+    if b is not None:
+        b = _dev(b, torch.float32, "b")
+        if b.shape[0] != B or b.shape[2] != N or b.shape[1] + Ca != 128:
+            raise ValueError("point_heads: a %s + b %s must make 128 channels" % (tuple(a.shape), tuple(b.shape)))
+    elif Ca != 128:
+        raise ValueError("point_heads: a must have 128 channels when b is None, got %d" % Ca)
+    n = len(layers)
+    vp, fp = ctypes.c_void_p, ctypes.c_void_p
+    w_arr = (vp * n)(*[l[0].data_ptr() for l in layers])
+    sc_arr = (fp * n)(*[(l[1].data_ptr() if l[1] is not None else None) for l in layers])
+    sh_arr = (fp * n)(*[(l[2].data_ptr() if l[2] is not None else None) for l in layers])
+    act_arr = (ctypes.c_int * n)(*[int(l[3]) for l in layers])
+    for l in layers:
+        if l[3] not in (ACT_NONE, ACT_RELU):
+            raise ValueError("point_heads: activations are none / ReLU")
+    wl, bl, c_last = last
+    out_feat = torch.empty((B, 128, N), dtype=torch.float32, device=a.device)
+    out_last = torch.empty((B, int(c_last), N), dtype=torch.float32, device=a.device)
+    check(_lib.lib().gdm_point_heads_hip(a.data_ptr(), b.data_ptr() if b is not None else None, Ca, B, N, n, w_arr, sc_arr, sh_arr, act_arr,
+                                         int(feat_layer), int(res_layer), wl.data_ptr(), bl.data_ptr() if bl is not None else None,
+                                         int(c_last), out_feat.data_ptr(), out_last.data_ptr(), _stream()), "gdm_point_heads_hip")
+    return out_feat, out_last
+
+
 def pack_rows64(w2d):
     """f32[R,64] -> R packed split-bf16 rows of 256 B (64 bf16 hi | 64 bf16 lo), u8 tensor."""
     w = _dev(w2d.detach(), torch.float32, "w")

@@ -415,6 +415,19 @@ int gdm_bn_bwd_reduce_hip(const float* x, const float* grad_out, const float* sa
 int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* sums, int groups, const float* weight, const float* saved, int B, int C,
                          long inner, int act, float slope, float* grad_weight, float* grad_bias, float* grad_x, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * The per-point heads of GeoMatch.forward in one kernel (inference; /root/reference/models/geoMatch.py:159-200: feature_encoding_layer,
+ * normalize_feature_layer, the residual add and seg_layer -- nine 1x1 convolutions per scene point).  Input x0 = channels of a
+ * f32[B,Ca,N] followed by b f32[B,128-Ca,N] (b may be NULL when Ca == 128).  `nlayer` hidden layers 128 -> 128:
+ *   x_{l+1} = act_l(scale_l * (W_l x_l) + shift_l)  [+ x0 after layer res_layer];  out_feat f32[B,128,N] = the affine output of layer
+ *   feat_layer (before the residual);  then out_last f32[B,c_last,N] = W_last x_nlayer + shift_last (c_last <= 16).
+ * w[l], w_last: weights packed by gdm_conv1x1_pack_weight_hip(Cout, 128) (rows padded to 128); scale[l] / shift[l] may be NULL (1 / 0);
+ * act[l]: 0 none, 1 ReLU; feat_layer / res_layer: -1 = none.  w, scale, shift, act are HOST arrays of nlayer entries.
+ * Split-bf16 products (hi*hi + hi*lo + lo*hi), fp32 accumulate, as the convolution kernels. */
+int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, int nlayer, const void* const* w,
+                        const float* const* scale, const float* const* shift, const int* act, int feat_layer, int res_layer,
+                        const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

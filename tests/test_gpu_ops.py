@@ -574,3 +574,42 @@ def test_fused_lfa_stage_equals_unfused_block(ops, d_out, n):
     assert got.shape == ref.shape == (B, d_out, n, 1)
     err = (got - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,N,Ca", [(2, 100, 128), (1, 2048, 64), (3, 64, 72)])
+def test_point_heads_chain_equals_the_layers_in_fp64(ops, B, N, Ca):
+    """The per-point heads of GeoMatch.forward as one launch (/root/reference/models/geoMatch.py:159-200: feature_encoding_layer x4,
+    normalize_feature_layer, + rgbd_emb, seg_layer x4) == the same chain of 1x1 convolutions, affine maps and ReLUs in fp64.
+    Ragged N (not a multiple of the 64-point workgroup), the input given whole or as two channel blocks."""
+    rs = np.random.RandomState(N + Ca)
+    x0 = torch.from_numpy(rs.randn(B, 128, N).astype(np.float32))
+    Ws = [torch.from_numpy((rs.randn(128, 128) / 11).astype(np.float32)) for _ in range(8)]
+    sc = [torch.from_numpy((rs.rand(128) + 0.5).astype(np.float32)) for _ in range(8)]
+    sh = [torch.from_numpy((rs.randn(128) * 0.3).astype(np.float32)) for _ in range(8)]
+    acts = [1, 1, 1, 0, 1, 1, 1, 1]
+    sc[3], sh[3] = None, None                                       # the fourth layer: no BN, no bias, no activation
+    w_last = torch.from_numpy((rs.randn(2, 128) / 11).astype(np.float32))
+    b_last = torch.from_numpy(rs.randn(2).astype(np.float32))
+    x = x0.double()
+    feat = None
+    for l in range(8):
+        y = torch.einsum("oc,bcn->bon", Ws[l].double(), x)
+        if sc[l] is not None:
+            y = y * sc[l].double()[None, :, None] + sh[l].double()[None, :, None]
+        if l == 3:
+            feat = y
+        if acts[l]:
+            y = y.clamp(min=0)
+        if l == 4:
+            y = x0.double() + y
+        x = y
+    seg = torch.einsum("oc,bcn->bon", w_last.double(), x) + b_last.double()[None, :, None]
+    layers = [(ops.gemm_pack_weight(Ws[l].cuda()), sc[l].cuda() if sc[l] is not None else None,
+               sh[l].cuda() if sh[l] is not None else None, acts[l]) for l in range(8)]
+    last = (ops.gemm_pack_weight(w_last.cuda()), b_last.cuda(), 2)
+    a = x0[:, :Ca].contiguous().cuda()
+    bq = x0[:, Ca:].contiguous().cuda() if Ca < 128 else None
+    got_feat, got_seg = ops.point_heads(a, bq, layers, last, feat_layer=3, res_layer=4)
+    assert got_feat.shape == (B, 128, N) and got_seg.shape == (B, 2, N)
+    assert (got_feat.cpu().double() - feat).abs().max().item() < 3e-5 * max(1.0, feat.abs().max().item())
+    assert (got_seg.cpu().double() - seg).abs().max().item() < 5e-5 * max(1.0, seg.abs().max().item())
