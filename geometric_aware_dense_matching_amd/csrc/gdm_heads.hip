@@ -53,9 +53,10 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
     const int b = blockIdx.y, n0 = blockIdx.x * HD_P;
     const int N = A.N, Ca = A.Ca, Cb = HD_C - A.Ca;
 
-    auto x0_at = [&](int c, int p) -> float {                     // input channel c of point n0 + p (0 beyond N)
-        if (n0 + p >= N) return 0.f;
-        return c < Ca ? A.a[((long)b * Ca + c) * N + n0 + p] : A.b[((long)b * Cb + (c - Ca)) * N + n0 + p];
+    auto x0_at = [&](int c, int p) -> float {                     // input channel c of point n0 + p (0 beyond N); no control flow
+        const float* src = c < Ca ? A.a + ((long)b * Ca + c) * N : A.b + ((long)b * Cb + (c - Ca)) * N;
+        const float v = src[min(n0 + p, N - 1)];
+        return n0 + p < N ? v : 0.f;
     };
 
     // ---- input rows: thread = (point, 8-channel group), lanes = consecutive points (coalesced channel rows) ----
