@@ -12,6 +12,8 @@
 //   att_pool       models/RandLA/RandLANet.py:749-752
 // and the lib/pointops signatures grouping / gathering (functions/pointops.py:61-82,151-176).
 #include "gdm_common.h"
+#include <stdlib.h>
+#include <stdint.h>
 #include <math.h>
 
 namespace {
@@ -78,6 +80,56 @@ __global__ __launch_bounds__(GB) void gather_max_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 1; k < KMAX; ++k) {
             const float v = f[nb[k]];
+            if (v > best) {
+                best = v;
+                bi = nb[k];
+            }
+        }
+        out[row * m + j] = best;
+        if (arg) arg[row * m + j] = bi;
+    }
+}
+
+// The same for LARGE source rows (pixel maps: random_sample of a 64x64 .. 128x128 feature map onto the points, ffb6d.py:128-146): the
+// kernel above reads K scattered floats per channel and output -- 4 useful bytes per 32-byte sector, the map fetched ~8x.  Here a
+// workgroup owns one (crop, channel) row: the row goes into LDS with one coalesced pass (<= 64 KiB), the gathers hit LDS, the
+// index rows are re-read per channel from L2 (16 B vector loads).  Same values, same first-maximum rule.
+template <int KMAX>
+__global__ __launch_bounds__(GB) void gather_max_rowlds_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                               int C, int n, int m, int K, float* __restrict__ out,
+                                                               int32_t* __restrict__ arg)
+{
+    extern __shared__ __attribute__((aligned(16))) float lrow[];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long row = (long)b * C + c;
+    const float* f = feat + row * n;
+    if ((n & 3) == 0 && (((uintptr_t)f) & 15) == 0) {
+        for (int i = threadIdx.x * 4; i < n; i += GB * 4) *reinterpret_cast<float4*>(lrow + i) = *reinterpret_cast<const float4*>(f + i);
+    } else {
+        for (int i = threadIdx.x; i < n; i += GB) lrow[i] = f[i];
+    }
+    __syncthreads();
+    const bool vec = KMAX == 16 && K == 16 && (((uintptr_t)idx) & 15) == 0;
+    for (int j = threadIdx.x; j < m; j += GB) {
+        const int32_t* ip = idx + ((long)b * m + j) * K;
+        int nb[KMAX];
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < KMAX / 4; ++q) {
+                const int4 v = *reinterpret_cast<const int4*>(ip + 4 * q);
+                nb[4 * q] = v.x; nb[4 * q + 1] = v.y; nb[4 * q + 2] = v.z; nb[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) nb[k] = k < K ? ip[k] : ip[0];
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) nb[k] = min(max(nb[k], 0), n - 1);
+        float best = lrow[nb[0]];
+        int bi = nb[0];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
+            const float v = lrow[nb[k]];
             if (v > best) {
                 best = v;
                 bi = nb[k];
@@ -349,6 +401,27 @@ extern "C" int gdm_gather_max_hip(const float* feat, const int32_t* idx, int B, 
     GDM_CHECK_ARG(K >= 1 && K <= 32, "gdm_gather_max_hip: K=%d not in [1,32]", K);
     dim3 grid(gdm_cdiv(m, GB), gdm_cdiv(C, CCHUNK), B);
     GDM_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gdm_gather_max_hip: grid too large");
+    // pixel-map sources: one workgroup per (crop, channel) row staged in LDS (GDM_GATHER_MAX_ROWLDS=0: the scattered form, for A/B)
+    static int rowlds = -1;
+    if (rowlds < 0) {
+        const char* e = getenv("GDM_GATHER_MAX_ROWLDS");
+        rowlds = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (rowlds && n >= 1024 && n <= 16384 && (long)m * K >= 2048 && C <= 65535) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gather_max_rowlds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gather_max_rowlds_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            attr = true;
+        }
+        dim3 g2(C, B);
+        const size_t lds = (size_t)((n + 3) & ~3) * 4;
+        if (K <= 16)
+            hipLaunchKernelGGL(gather_max_rowlds_kernel<16>, g2, dim3(GB), lds, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+        else
+            hipLaunchKernelGGL(gather_max_rowlds_kernel<32>, g2, dim3(GB), lds, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+        return gdm_launch_status("gather_max_rowlds_kernel");
+    }
     if (K <= 16)
         hipLaunchKernelGGL(gather_max_kernel<16>, grid, dim3(GB), 0, STREAM(stream), feat, idx, C, n, m, K, out, arg);
     else

@@ -147,7 +147,8 @@ def _feat_idx(rs, B, C, n, m, K):
     return feat, idx
 
 
-@pytest.mark.parametrize("B,C,n,m,K", [(2, 64, 2048, 512, 16), (1, 3, 100, 37, 5), (2, 129, 300, 300, 16), (2, 64, 4096, 128, 16)])
+@pytest.mark.parametrize("B,C,n,m,K", [(2, 64, 2048, 512, 16), (1, 3, 100, 37, 5), (2, 129, 300, 300, 16), (2, 64, 4096, 128, 16),
+                                       (2, 64, 16384, 2048, 16), (1, 5, 1027, 300, 7), (1, 2, 16384, 129, 20), (1, 3, 16385, 200, 16)])
 def test_gather_max(ops, B, C, n, m, K):
     from oracle import ops_ref
     feat, idx = _feat_idx(np.random.RandomState(1), B, C, n, m, K)
