@@ -337,7 +337,7 @@ def extra_legs(torch, dev, args, model, N, M):
 def main():
     args = parse()
     if args.exact_f32:                      # read by the package at import time
-        for env in ("GDM_MFMA_CONV", "GDM_MFMA_GEMM", "GDM_FUSED_UPCONV", "GDM_SPARSE_FINAL", "GDM_FUSED_HEADS"):
+        for env in ("GDM_MFMA_CONV", "GDM_MFMA_GEMM", "GDM_FUSED_UPCONV", "GDM_SPARSE_FINAL", "GDM_FUSED_HEADS", "GDM_MFMA_STRIDED"):
             os.environ[env] = "0"              # every split-bf16 product path off (settings.SPLIT_BF16_SWITCHES)
         args.precision = "f32"
     import numpy as np

@@ -63,11 +63,14 @@ class BasicBlock(nn.Module):
     def _train_conv(conv, x):
         """Training: forward and input gradient of the 32x32-resolution 3x3 convolutions on the split-bf16 MFMA kernel (MIOpen's fp32
         Winograd runs them 3x slower); the weight gradient stays with MIOpen."""
-        if settings.USE_MFMA_CONV_TRAIN and conv.bias is None and ops.conv3x3_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation):
+        if (settings.USE_MFMA_CONV_TRAIN and conv.bias is None and tuple(conv.stride) == (1, 1)
+                and ops.conv3x3_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation)):
             return ops.conv3x3_train(x, conv.weight)
         return conv(x)
 
     def _mfma_ok(self, x):
+        if tuple(self.conv1.stride) != (1, 1) and not settings.USE_MFMA_STRIDED:
+            return False
         return (settings.USE_MFMA_CONV and ops.conv3x3_supported(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation)
                 and ops.conv3x3_supported(x, self.conv2.weight, self.conv2.stride, self.conv2.padding, self.conv2.dilation)
                 and self.conv2.weight.shape[1] == self.conv1.weight.shape[0])
@@ -81,18 +84,31 @@ class BasicBlock(nn.Module):
             # chain of blocks.
             s1, b1 = folded_bn(self.bn1)
             planes = self.conv1.weight.shape[0]
+            stride = self.conv1.stride[0]
             xin = getattr(x, "_gdm_packed", None)
             if xin is None or xin.shape != tuple(x.shape):
                 xin = x
-            chain = (x.shape[0] * x.shape[2] * x.shape[3]) % 256 == 0
-            mid = ops.conv3x3_bf16x3(xin, self._packed_weight(self.conv1), planes, s1, b1, ops.ACT_RELU, out_f32=not chain, out_packed=chain)
+            dconv = self.downsample[0] if self.downsample is not None else None
+            own_ds = (settings.USE_MFMA_STRIDED and dconv is not None and isinstance(dconv, nn.Conv2d) and dconv.kernel_size == (1, 1) and dconv.bias is None
+                      and dconv.stride == self.conv1.stride and dconv.padding == (0, 0)
+                      and ops.gemm_supported(dconv.in_channels, dconv.out_channels, 64))
+            if own_ds and not isinstance(xin, ops.PackedAct):
+                xin = ops.conv3x3_pack_act(x)                      # one packed operand feeds conv1 and the downsample branch
+            chain = (x.shape[0] * (x.shape[2] // stride) * (x.shape[3] // stride)) % 256 == 0
+            mid = ops.conv3x3_bf16x3(xin, self._packed_weight(self.conv1), planes, s1, b1, ops.ACT_RELU, out_f32=not chain, out_packed=chain,
+                                     stride=stride)
             mid = mid[1] if chain else mid
             s2, b2 = folded_bn(self.bn2)
             if self.downsample is None:
                 res = x
             else:
                 sd, bd = folded_bn(self.downsample[1])
-                res = ops.affine_act(self.downsample[0](x), sd, bd, ops.ACT_NONE)
+                if own_ds:
+                    # 1x1 (strided) convolution + BN on the same kernel, reading the packed map conv1 reads
+                    wd, _ = cached_gemm_weight(dconv, "ds", lambda: dconv.weight.reshape(dconv.out_channels, dconv.in_channels), (dconv.weight,))
+                    res = ops.conv1x1_packed2d(xin, wd, dconv.out_channels, sd, bd, ops.ACT_NONE, stride=stride)
+                else:
+                    res = ops.affine_act(dconv(x), sd, bd, ops.ACT_NONE)
             if not chain:
                 return ops.conv3x3_bf16x3(mid, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res)
             out, opk = ops.conv3x3_bf16x3(mid, self._packed_weight(self.conv2), planes, s2, b2, ops.ACT_RELU, res, out_packed=True)

@@ -352,8 +352,9 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                                                                  const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
                                                                  float* __restrict__ out, const int32_t* __restrict__ rowidx = nullptr,
                                                                  const int32_t* __restrict__ tile_co0 = nullptr,
-                                                                 unsigned char* __restrict__ outpk = nullptr)
+                                                                 unsigned char* __restrict__ outpk = nullptr, int stride = 1)
 {
+    // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     constexpr int NS = NKS / 2;                                     // k-steps of 32 channels per chunk
     constexpr int NPH = MF_NPH;
@@ -368,13 +369,15 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const long pc = min(pix0, ptot - MF_WPIX);
     const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
     const int prem = (int)(pc - (long)b * hw);
-    const long plane = (long)(H + 2) * (W + 2);
+    const int Wi = W * stride;
+    const long plane = (long)(H * stride + 2) * (Wi + 2);           // input planes (operand loads)
+    const long oplane = (long)(H + 2) * (W + 2);                    // output planes (packed epilogue)
     long pixbase[NPH];                                              // fragment ph: 16 consecutive pixels of one image row (W % 16 == 0)
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int pr = prem + 16 * ph;
         const int yy = pr / W, xx = pr - yy * W;
-        pixbase[ph] = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)yy * (W + 2) + xx + l16;
+        pixbase[ph] = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)(yy * stride) * (Wi + 2) + (long)(xx + l16) * stride;
     }
 
     u32x4 ahi[NS][NPH], alo[NS][NPH];                               // fragments of k-step S, pixel fragment ph
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         const int tap = (TAPS == 1) ? 4 : it / nchunk;
         const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
         const int ky = tap / 3, kx = tap - ky * 3;
-        return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + kg) * plane + (long)ky * (W + 2) + kx) * 16;
+        return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + kg) * plane + (long)ky * (Wi + 2) + kx) * 16;
     };
     const long sstride = 4 * plane * 16;                            // plane 4 S + kg -> 4 (S + 1) + kg
     const long lostride = 16 * plane * 16;                          // hi plane q -> lo plane 16 + q
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         for (int half = 0; half < MF_WPIX / 32; ++half) {
             const int pp = prem + 32 * half + lr;                    // this lane's pixel of the wave's tile
             const int yy = pp / W, xx = pp - yy * W;
-            unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * plane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
+            unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * oplane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
             const float* row = tl + (32 * half + lr) * MF_TSTRIDE;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -560,8 +563,8 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                 const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 unsigned hi[4], lo[4];
                 split8(v, hi, lo);
-                *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                *reinterpret_cast<uint4*>(ob + (long)q * oplane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(ob + (long)(16 + q) * oplane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             }
         }
     }
@@ -632,9 +635,26 @@ extern "C" int gdm_conv3x3_pack_act_hip(const float* x, int B, int Cin, int H, i
 
 // out (fp32 NCHW) and / or outpk (the packed operand of the next convolution over [B, Cout, H, W]; zero-filled once by the caller, only
 // interior pixels are written) -- at least one of them.
+static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                          int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* outpk, void* stream);
+
 extern "C" int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                                        int B, int Cin, int Cout, int H, int W, int act, float* out, void* outpk, void* stream)
 {
+    return conv3x3_launch(xpk, wpk, scale, shift, res, B, Cin, Cout, H, W, 1, act, out, outpk, stream);
+}
+
+// H, W = OUTPUT size; xpk = the (H stride) x (W stride) input packed by gdm_conv3x3_pack_act_hip; stride 1 or 2
+extern "C" int gdm_conv3x3_strided_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                                       int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* outpk, void* stream)
+{
+    return conv3x3_launch(xpk, wpk, scale, shift, res, B, Cin, Cout, H, W, stride, act, out, outpk, stream);
+}
+
+static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                          int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* outpk, void* stream)
+{
+    GDM_CHECK_ARG(stride == 1 || (stride == 2 && GDM_CONV_SHAPE == 16), "gdm_conv3x3: stride=%d (1, or 2 on the 16x16x32 kernel)", stride);
     GDM_CHECK_ARG(xpk && wpk && (out || outpk), "gdm_conv3x3_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
     GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CONV_WPIX == 0,
@@ -658,7 +678,11 @@ extern "C" int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const f
         (void)hipFuncSetAttribute((const void*)CONV_KERNEL<1, true, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr = true;
     }
+#if GDM_CONV_SHAPE == 16
+#define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
+#else
 #define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
+#endif
     if (Cin == 64) {                                             // one half-filled chunk: only its four non-zero k-steps are run
         if (act == 0) { if (res) CV(0, true, 4); else CV(0, false, 4); }
         else { if (res) CV(1, true, 4); else CV(1, false, 4); }
@@ -698,9 +722,26 @@ extern "C" int gdm_gemm_grouped_hip(const void* xpk, const void* wpk, const int3
 
 // 1x1 convolution / GEMM on the same kernel (one tap): out = act(scale * (W x) + shift), x packed by gdm_conv3x3_pack_act_hip.
 // pixel_major != 0 writes out[B*H*W, Cout] (row per pixel) instead of NCHW.
+static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                          int B, int Cin, int Cout, int H, int W, int stride, int act, int pixel_major, float* out, void* stream);
+
 extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
                                       int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream)
 {
+    return conv1x1_launch(xpk, wpk, scale, shift, B, Cin, Cout, H, W, 1, act, pixel_major, out, stream);
+}
+
+// H, W = OUTPUT size; xpk = the (H stride) x (W stride) input (the downsample branch of a strided residual block reads every other pixel)
+extern "C" int gdm_conv1x1_strided_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                                       int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* stream)
+{
+    return conv1x1_launch(xpk, wpk, scale, shift, B, Cin, Cout, H, W, stride, act, 0, out, stream);
+}
+
+static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                          int B, int Cin, int Cout, int H, int W, int stride, int act, int pixel_major, float* out, void* stream)
+{
+    GDM_CHECK_ARG(stride == 1 || (stride == 2 && GDM_CONV_SHAPE == 16), "gdm_conv1x1: stride=%d (1, or 2 on the 16x16x32 kernel)", stride);
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
     GDM_CHECK_ARG(Cin != 64 || !pixel_major, "gdm_conv1x1_packed_hip: Cin=64 is built for the NCHW output only");
@@ -721,12 +762,17 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
         attr = true;
     }
     if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
-#define C1H(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 4>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+#if GDM_CONV_SHAPE == 16
+#define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride
+#else
+#define C1TAIL
+#endif
+#define C1H(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 4>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
         if (act == 0) C1H(0); else C1H(1);
 #undef C1H
         return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
-#define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out)
+#define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
     if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }
     else { if (pixel_major) C1(1, true); else C1(1, false); }
 #undef C1

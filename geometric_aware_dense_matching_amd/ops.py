@@ -947,10 +947,15 @@ _conv_act_cache = {}
 
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1)):
+    """3x3 / pad 1 / no dilation, stride 1 or 2 (output width a multiple of 32), Cin 64 or a multiple of 128."""
     cin = weight.shape[1]
+    st = tuple(stride)
+    if st not in ((1, 1), (2, 2)):
+        return False
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-            and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1)
-            and (cin == 64 or cin % 128 == 0) and weight.shape[0] % 8 == 0 and x.shape[3] % 32 == 0 and x.shape[0] <= 65535)
+            and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1)
+            and x.shape[2] % st[0] == 0 and x.shape[3] % st[1] == 0 and (x.shape[3] // st[1]) % 32 == 0
+            and (cin == 64 or cin % 128 == 0) and weight.shape[0] % 8 == 0 and x.shape[0] <= 65535)
 
 
 def conv3x3_pack_weight(weight):
@@ -994,12 +999,16 @@ def conv3x3_pack_act(x):
     return PackedAct(buf, (B, C, H, W))
 
 
-def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None, out_f32=True, out_packed=False):
-    """3x3/s1/p1 convolution of x f32[B,Cin,H,W] (or a PackedAct) with packed weights on split-bf16 MFMA (+ per-channel scale/shift,
-    optional residual, optional ReLU).  Returns the fp32 map, or -- out_packed -- (fp32 map or None, PackedAct of the result): the
-    epilogue writes the next convolution's operand itself.  Inference only."""
+def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None, out_f32=True, out_packed=False, stride=1):
+    """3x3/p1 convolution (stride 1 or 2) of x f32[B,Cin,H,W] (or a PackedAct) with packed weights on split-bf16 MFMA (+ per-channel
+    scale/shift, optional residual, optional ReLU).  Returns the fp32 map, or -- out_packed -- (fp32 map or None, PackedAct of the
+    result): the epilogue writes the next convolution's operand itself.  Inference only."""
     xp = x if isinstance(x, PackedAct) else conv3x3_pack_act(x)
     B, Cin, H, W = xp.shape
+    if stride != 1:
+        if stride != 2 or H % 2 or W % 2:
+            raise ValueError("conv3x3_bf16x3: stride %r on a %dx%d map" % (stride, H, W))
+        H, W = H // 2, W // 2
     L = _lib.lib()
     dev = xp.buf.device
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev) if out_f32 else None
@@ -1011,11 +1020,25 @@ def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None,
     if res is not None:
         res = _dev(res, torch.float32, "res")
         assert tuple(res.shape) == (B, cout, H, W)
-    check(L.gdm_conv3x3_packed2_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
+    check(L.gdm_conv3x3_strided_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
                                     shift.data_ptr() if shift is not None else None, res.data_ptr() if res is not None else None,
-                                    B, Cin, cout, H, W, act, out.data_ptr() if out is not None else None,
-                                    opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_conv3x3_packed2_hip")
+                                    B, Cin, cout, H, W, int(stride), act, out.data_ptr() if out is not None else None,
+                                    opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_conv3x3_strided_hip")
     return (out, opk) if out_packed else out
+
+
+def conv1x1_packed2d(xp, wpk, cout, scale=None, shift=None, act=ACT_NONE, stride=1):
+    """1x1 convolution (stride 1 or 2) of a PackedAct map with gemm_pack_weight'ed weights -> f32[B,cout,H/stride,W/stride]: the
+    downsample branch of a residual block on the packed operand its 3x3 convolution already reads.  Inference only."""
+    B, Cin, H, W = xp.shape
+    if stride not in (1, 2) or H % stride or W % stride:
+        raise ValueError("conv1x1_packed2d: stride %r on a %dx%d map" % (stride, H, W))
+    H, W = H // stride, W // stride
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=xp.buf.device)
+    check(_lib.lib().gdm_conv1x1_strided_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                             shift.data_ptr() if shift is not None else None, B, Cin, cout, H, W, int(stride), act,
+                                             out.data_ptr(), _stream()), "gdm_conv1x1_strided_hip")
+    return out
 
 
 class _Conv3x3Train(torch.autograd.Function):

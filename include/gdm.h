@@ -362,6 +362,13 @@ int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale,
  * (outpk: gdm_conv3x3_act_bytes(B, Cout, H, W) bytes, zero-filled once by the caller), which then needs no pack launch.  */
 int gdm_conv3x3_packed2_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                             int B, int Cin, int Cout, int H, int W, int act, float* out, void* outpk, void* stream);
+/* Strided forms (stride 1 or 2; the first block of ResNet-18 layer2, extractors.py:151-177): H, W are the OUTPUT size, xpk is the
+ * (H*stride) x (W*stride) input packed by gdm_conv3x3_pack_act_hip; gdm_conv1x1_strided_hip is the block's 1x1 downsample branch
+ * on the same packed input (NCHW output). */
+int gdm_conv3x3_strided_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
+                            int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* outpk, void* stream);
+int gdm_conv1x1_strided_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
+                            int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* stream);
 
 /* `final` stage of the image branch (pspnet.py:108-112): out = log_softmax_c(W x + b), x,out f32[B,64,hw], W f32[64,64]. */
 int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream);

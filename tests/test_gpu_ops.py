@@ -614,3 +614,39 @@ def test_point_heads_chain_equals_the_layers_in_fp64(ops, B, N, Ca):
     assert got_feat.shape == (B, 128, N) and got_seg.shape == (B, 2, N)
     assert (got_feat.cpu().double() - feat).abs().max().item() < 3e-5 * max(1.0, feat.abs().max().item())
     assert (got_seg.cpu().double() - seg).abs().max().item() < 5e-5 * max(1.0, seg.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 128, 64, 64), (1, 128, 256, 16, 64), (3, 256, 64, 8, 128)])
+def test_strided_conv3x3_and_conv1x1_downsample_vs_fp64(ops, B, Cin, Cout, H, W):
+    """Stride-2 forms of the implicit-GEMM kernel (first block of ResNet-18 layer2, /root/reference/models/cnn/extractors.py:151-177):
+    3x3 / pad 1 / stride 2 with BN + ReLU in the epilogue, fp32 and packed outputs, and the 1x1 / stride 2 downsample branch on the
+    same packed input == F.conv2d in fp64."""
+    rs = np.random.RandomState(Cin + W)
+    x = torch.from_numpy(rs.randn(B, Cin, H, W).astype(np.float32))
+    w3 = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / np.sqrt(9 * Cin)).astype(np.float32))
+    w1 = torch.from_numpy((rs.randn(Cout, Cin) / np.sqrt(Cin)).astype(np.float32))
+    scale = torch.from_numpy((rs.rand(Cout) + 0.5).astype(np.float32))
+    shift = torch.from_numpy(rs.randn(Cout).astype(np.float32))
+    ref3 = torch.nn.functional.conv2d(x.double(), w3.double(), stride=2, padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    ref3 = ref3.clamp(min=0)
+    ref1 = torch.nn.functional.conv2d(x.double(), w1.double()[:, :, None, None], stride=2) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    assert ops.conv3x3_supported(x.cuda(), w3.cuda(), (2, 2))
+    xp = ops.conv3x3_pack_act(x.cuda())
+    got = ops.conv3x3_bf16x3(xp, ops.conv3x3_pack_weight(w3.cuda()), Cout, scale.cuda(), shift.cuda(), ops.ACT_RELU, stride=2)
+    assert got.shape == (B, Cout, H // 2, W // 2)
+    tol = 3e-5 * max(1.0, ref3.abs().max().item())
+    assert (got.cpu().double() - ref3).abs().max().item() < tol
+    if (B * (H // 2) * (W // 2)) % 256 == 0:
+        # packed output of the strided convolution feeds a stride-1 convolution (conv1 -> conv2 of the block)
+        _, opk = ops.conv3x3_bf16x3(xp, ops.conv3x3_pack_weight(w3.cuda()), Cout, scale.cuda(), shift.cuda(), ops.ACT_RELU, out_f32=False,
+                                    out_packed=True, stride=2)
+        if Cout == 64 or Cout % 128 == 0:
+            w2 = torch.from_numpy((rs.randn(64, Cout, 3, 3) / np.sqrt(9 * Cout)).astype(np.float32))
+            ref2 = torch.nn.functional.conv2d(ref3, w2.double(), padding=1)
+            got2 = ops.conv3x3_bf16x3(opk, ops.conv3x3_pack_weight(w2.cuda()), 64)
+            assert (got2.cpu().double() - ref2).abs().max().item() < 5e-5 * max(1.0, ref2.abs().max().item())
+    got1 = ops.conv1x1_packed2d(xp, ops.gemm_pack_weight(w1.cuda()), Cout, scale.cuda(), shift.cuda(), ops.ACT_NONE, stride=2)
+    assert (got1.cpu().double() - ref1).abs().max().item() < 3e-5 * max(1.0, ref1.abs().max().item())
+    got1s = ops.conv1x1_packed2d(xp, ops.gemm_pack_weight(w1.cuda()), Cout, None, None, ops.ACT_NONE, stride=1)
+    ref1s = torch.nn.functional.conv2d(x.double(), w1.double()[:, :, None, None])
+    assert (got1s.cpu().double() - ref1s).abs().max().item() < 3e-5 * max(1.0, ref1s.abs().max().item())
