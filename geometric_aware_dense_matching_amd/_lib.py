@@ -98,6 +98,7 @@ SIGNATURES = {
     "gdm_conv3x3_packed2_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_conv3x3_strided_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_conv1x1_strided_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_affine_relu_maxpool_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_conv1x1_logsoftmax_hip": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp]),
     "gdm_psp_pools_hip": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gdm_bn_sums_len": (ctypes.c_long, [_i, _i, ctypes.c_long]),

@@ -1064,6 +1064,44 @@ extern "C" int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, c
     return gdm_conv1x1_gather_add_act2_hip(x, wt, t, idx, scale, shift, B, C, n, m, act, slope, 0, y, stream);
 }
 
+// ResNet stem tail: BatchNorm (folded) + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass over the 7x7 convolution's output
+// (extractors.py:128-131): the two-kernel form writes and re-reads the 2x-resolution activated map.  Thread = output pixel.
+__global__ __launch_bounds__(256) void affine_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int C, int H, int W, int OH, int OW,
+                                                                  float* __restrict__ y)
+{
+    const int plane = blockIdx.y;                                 // b * C + c
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= OH * OW) return;
+    const int oy = o / OW, ox = o - oy * OW;
+    const int c = plane % C;
+    const float sc = scale[c], sh = shift[c];
+    const float* xp = x + (long)plane * H * W;
+    float best = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = 2 * oy - 1 + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = 2 * ox - 1 + dx;
+            if (xx < 0 || xx >= W) continue;
+            best = fmaxf(best, fmaxf(fmaf(xp[(long)yy * W + xx], sc, sh), 0.f));
+        }
+    }
+    y[(long)plane * OH * OW + o] = best;
+}
+
+extern "C" int gdm_affine_relu_maxpool_hip(const float* x, const float* scale, const float* shift, int B, int C, int H, int W, float* y, void* stream)
+{
+    GDM_CHECK_ARG(x && scale && shift && y, "gdm_affine_relu_maxpool_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && C >= 1 && H >= 1 && W >= 1 && (long)B * C <= 65535, "gdm_affine_relu_maxpool_hip: bad shape");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;          // floor((H + 2 - 3) / 2) + 1
+    hipLaunchKernelGGL(affine_relu_maxpool_kernel, dim3(gdm_cdiv((long)OH * OW, 256), B * C), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       C, H, W, OH, OW, y);
+    return gdm_launch_status("affine_relu_maxpool_kernel");
+}
+
 extern "C" int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream)
 {
     GDM_CHECK_ARG(x && w && out, "gdm_conv1x1_logsoftmax_hip: NULL pointer");

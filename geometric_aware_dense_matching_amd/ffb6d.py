@@ -154,7 +154,13 @@ class FFB6DEmb(nn.Module):
         if fused_eval(inputs["rgb"], self):
             pre = self.cnn_pre_stages                                         # conv1, bn1, relu, maxpool
             s0, b0 = folded_bn(pre[1])
-            rgb_emb = pre[3](ops.affine_act(pre[0](inputs["rgb"]), s0, b0, ops.ACT_RELU))
+            mp = pre[3]
+            y0 = pre[0](inputs["rgb"])
+            if (isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (3, (3, 3)) and mp.stride in (2, (2, 2)) and mp.padding in (1, (1, 1))
+                    and mp.dilation in (1, (1, 1)) and not mp.ceil_mode and isinstance(pre[2], nn.ReLU) and y0.shape[0] * y0.shape[1] <= 65535):
+                rgb_emb = ops.affine_relu_maxpool(y0, s0, b0)          # BN + ReLU + max-pool: one pass over the stem's map
+            else:
+                rgb_emb = mp(ops.affine_act(y0, s0, b0, ops.ACT_RELU))
         else:
             pre = self.cnn_pre_stages
             rgb_emb = pre[3](bn_act(pre[1], pre[0](inputs["rgb"]), pre[2]))

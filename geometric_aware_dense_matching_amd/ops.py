@@ -844,6 +844,16 @@ def upconv_final_points(x_pm, hw, choose, wpk, scale, shift, act, slope, wf_pk, 
 _final_wt_cache = {}
 
 
+def affine_relu_maxpool(x, scale, shift):
+    """MaxPool2d(3, 2, 1)(relu(scale[c] * x + shift[c])) in one pass (the ResNet stem behind conv1).  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(_lib.lib().gdm_affine_relu_maxpool_hip(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, C, H, W, y.data_ptr(), _stream()),
+          "gdm_affine_relu_maxpool_hip")
+    return y
+
+
 def conv1x1_logsoftmax(x, weight, bias):
     """log_softmax over channels of a 64->64 1x1 convolution, one pass (the `final` stage, pspnet.py:108-112). Inference only."""
     x = _dev(x, torch.float32, "x")

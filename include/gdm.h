@@ -371,6 +371,9 @@ int gdm_conv1x1_strided_hip(const void* xpk, const void* wpk, const float* scale
                             int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* stream);
 
 /* `final` stage of the image branch (pspnet.py:108-112): out = log_softmax_c(W x + b), x,out f32[B,64,hw], W f32[64,64]. */
+/* ResNet stem tail in one pass (extractors.py:128-131 after conv1): y = MaxPool2d(3, stride 2, padding 1)(relu(scale[c] * x + shift[c])),
+ * x f32[B,C,H,W] -> y f32[B,C,(H-1)/2+1,(W-1)/2+1]; scale / shift = eval-mode BatchNorm folded. */
+int gdm_affine_relu_maxpool_hip(const float* x, const float* scale, const float* shift, int B, int C, int H, int W, float* y, void* stream);
 int gdm_conv1x1_logsoftmax_hip(const float* x, const float* w, const float* bias, int B, int C, long hw, float* out, void* stream);
 /* The last image stage of FFB6DEmb at the SAMPLED pixels only (inference; /root/reference/models/ffb6d.py:266-285: cnn_up_stages[3] =
  * PSPUpsample(64 -> 64) + `final`, then torch.gather with `choose`): out f32[B,64,N] = log_softmax(Wf . act(scale * conv3x3(up(x)) +

@@ -650,3 +650,17 @@ def test_strided_conv3x3_and_conv1x1_downsample_vs_fp64(ops, B, Cin, Cout, H, W)
     got1s = ops.conv1x1_packed2d(xp, ops.gemm_pack_weight(w1.cuda()), Cout, None, None, ops.ACT_NONE, stride=1)
     ref1s = torch.nn.functional.conv2d(x.double(), w1.double()[:, :, None, None])
     assert (got1s.cpu().double() - ref1s).abs().max().item() < 3e-5 * max(1.0, ref1s.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 128, 128), (1, 3, 7, 9), (2, 5, 16, 6)])
+def test_affine_relu_maxpool_equals_modules(ops, B, C, H, W):
+    """BN (folded) + ReLU + MaxPool2d(3, 2, 1) in one pass == the three modules (stem of /root/reference/models/cnn/extractors.py:128-131);
+    odd sizes exercise the pool's padding at both ends.  Selection + one fma: exact against the same fp32 arithmetic."""
+    rs = np.random.RandomState(H * W)
+    x = torch.from_numpy(rs.randn(B, C, H, W).astype(np.float32)).cuda()
+    scale = torch.from_numpy((rs.rand(C) + 0.5).astype(np.float32)).cuda()
+    shift = torch.from_numpy(rs.randn(C).astype(np.float32)).cuda()
+    ref = torch.nn.functional.max_pool2d(torch.relu(torch.addcmul(shift[None, :, None, None], x, scale[None, :, None, None])), 3, 2, 1)
+    got = ops.affine_relu_maxpool(x, scale, shift)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
