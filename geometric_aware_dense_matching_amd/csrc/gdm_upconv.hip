@@ -579,6 +579,117 @@ __global__ __launch_bounds__(256, 4) void upconv_final_points_kernel(const float
     }
 }
 
+// The 64-channel point->pixel fusion (ffb6d.py:216-222,252-258) on the matrix cores: y[b,co,j] = act(scale[co] * (sum_ci W[co,ci] x[b,ci,j]
+// + t[b,co,idx[b,j]]) + shift[co]).  conv1x1_gather_add_act_kernel (gdm_image.hip) does the K = 64 mix with 4096 fp32 FMAs per pixel
+// and is bound by them (58 us at 128^2 x 16); here a workgroup splits 64 pixels x 64 channels into operand rows in LDS, a wave forms
+// 16 output channels x 64 pixels with 24 MFMAs (split-bf16 x3) and adds the gathered point term on the accumulators, which leaves the
+// read and the write of the map.  Output NCHW, or pixel-major [B, m, 64] for the sampled-pixel final stage.
+constexpr int CG_P = 64;
+// TPM: the point term arrives point-major, t f32[B, n, 64] (one 16-byte load per pixel and lane instead of four scattered floats)
+template <int ACT, bool PM, bool TPM>
+__global__ __launch_bounds__(256, 4) void conv64_gather_add_act_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
+                                                                          const float* __restrict__ t, const int32_t* __restrict__ idx,
+                                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                          int n, int m, float slope, float* __restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char rows[CG_P * UF_ROWB];      // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y, j0 = blockIdx.x * CG_P;
+    const float* xb = x + (long)b * UF_C * m;
+    // A fragments (weights): rows 16 wave + l16, k-step S: channels 32 S + 8 kg ..
+    u32x4 wh[2], wl[2];
+    {
+        const unsigned char* r = wpk + (long)(16 * wave + l16) * UF_ROWB;
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            wh[S] = *reinterpret_cast<const u32x4*>(r + (4 * S + kg) * 16);
+            wl[S] = *reinterpret_cast<const u32x4*>(r + (8 + 4 * S + kg) * 16);
+        }
+    }
+    // operand rows: thread = (pixel, 8-channel group), lanes = consecutive pixels; loads without control flow
+    {
+        float raw[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = i * 256 + tid;
+            const int p = item & (CG_P - 1), grp = item >> 6;
+            const int pp = min(j0 + p, m - 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) raw[i][c] = xb[(long)(grp * 8 + c) * m + pp];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = i * 256 + tid;
+            const int p = item & (CG_P - 1), grp = item >> 6;
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gdm_split2(raw[i][2 * c], raw[i][2 * c + 1], hi[c], lo[c]);
+            *reinterpret_cast<u32x4*>(rows + uf_off(p, grp)) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(rows + uf_off(p, 8 + grp)) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+    // the gathered point term of this lane's pixels and channels, in flight during the products
+    const int c0 = 16 * wave + 4 * kg;
+    float tv[4][4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int j = min(j0 + 16 * pb + l16, m - 1);
+        int src = idx[(long)b * m + j];
+        src = min(max(src, 0), n - 1);
+        if (TPM) {
+            const float4 q = *reinterpret_cast<const float4*>(t + ((long)b * n + src) * UF_C + c0);
+            tv[pb][0] = q.x; tv[pb][1] = q.y; tv[pb][2] = q.z; tv[pb][3] = q.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[pb][r] = t[((long)b * UF_C + c0 + r) * n + src];
+        }
+    }
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc[r] = scale[c0 + r];
+        sh[r] = shift[c0 + r];
+    }
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(4))) float f32x4w;
+    f32x4w acc[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        acc[pb] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rows + uf_off(16 * pb + l16, 4 * S + kg)));
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rows + uf_off(16 * pb + l16, 8 + 4 * S + kg)));
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[S]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, wl[S]);
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc[pb], 0, 0, 0);
+        }
+    }
+    // accumulator: lane column l16 = pixel 16 pb + l16, registers r = channels c0 + r
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int j = j0 + 16 * pb + l16;
+        if (j >= m) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = sc[r] * (acc[pb][r] + tv[pb][r]) + sh[r];
+            if (ACT == 1) v = fmaxf(v, 0.f);
+            if (ACT == 2) v = v > 0.f ? v : v * slope;
+            o[r] = v;
+        }
+        if (PM) {
+            *reinterpret_cast<float4*>(y + ((long)b * m + j) * UF_C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[((long)b * UF_C + c0 + r) * m + j] = o[r];
+        }
+    }
+}
+
 // w f32[R, 64] -> R rows of 256 B: 64 bf16 hi | 64 bf16 lo
 __global__ __launch_bounds__(256) void pack_rows64_kernel(const float* __restrict__ w, int R, unsigned char* __restrict__ out)
 {
@@ -674,4 +785,21 @@ extern "C" int gdm_upconv_final_points_hip(const float* xpm, const int32_t* choo
     if (act == 0) FPK(0); else if (act == 1) FPK(1); else FPK(2);
 #undef FPK
     return gdm_launch_status("upconv_final_points_kernel");
+}
+
+extern "C" int gdm_conv64_gather_add_act_mfma_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
+                                                  const float* shift, int B, int n, long m, int act, float slope, int pixel_major,
+                                                  int t_point_major, float* y, void* stream)
+{
+    GDM_CHECK_ARG(x && wpk && t && idx && scale && shift && y, "gdm_conv64_gather_add_act_mfma_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1 && m >= 1 && m <= 0x7fffffffL && act >= 0 && act <= 2, "gdm_conv64_gather_add_act_mfma_hip: bad shape");
+    dim3 grid(gdm_cdiv(m, CG_P), B);
+    hipStream_t s = (hipStream_t)stream;
+#define CGM(A, P, T) hipLaunchKernelGGL((conv64_gather_add_act_mfma_kernel<A, P, T>), grid, dim3(256), 0, s, x, (const unsigned char*)wpk, t, idx, scale, shift, n, (int)m, slope, y)
+#define CGA(A) do { if (pixel_major) { if (t_point_major) CGM(A, true, true); else CGM(A, true, false); } \
+                    else { if (t_point_major) CGM(A, false, true); else CGM(A, false, false); } } while (0)
+    if (act == 0) CGA(0); else if (act == 1) CGA(1); else CGA(2);
+#undef CGA
+#undef CGM
+    return gdm_launch_status("conv64_gather_add_act_mfma_kernel");
 }

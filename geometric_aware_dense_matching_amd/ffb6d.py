@@ -128,6 +128,20 @@ class FFB6DEmb(nn.Module):
             code = act_code(getattr(fuse_layer, "activation", None))
             if code is not None:
                 wa, wb = self._split_fuse_weight(fuse_layer, c)
+                if c == 64 and wa.shape[0] == 64 and settings.USE_MFMA_GEMM:
+                    # K = 64: channel mix on the matrix cores (split-bf16 x3) + gather + add + BN + ReLU in ONE pass over the pixels,
+                    # bound by the map's read + write; the point term is formed point-major ([B, n', 64]: one contiguous row per
+                    # gathered point) by the same library GEMM with its operands swapped
+                    scale, shift = folded_bn(fuse_layer.normlayer.bn)
+                    pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
+                    t_pm = torch.matmul(pp.transpose(1, 2), wb.t())                       # [B, n', 64]
+                    cache = fuse_layer.__dict__.get("_gdm_wa_pk")
+                    if cache is None or cache[0] is not wa:
+                        cache = (wa, ops.pack_rows64(wa))
+                        fuse_layer.__dict__["_gdm_wa_pk"] = cache
+                    y = ops.conv64_gather_add_act_mfma(rgb_emb0.reshape(bs, c, hr * wr), cache[1], t_pm, idx.reshape(bs, -1), scale, shift,
+                                                       code[0], code[1], pixel_major=pixel_major, t_point_major=True)
+                    return y if pixel_major else y.view(bs, -1, hr, wr)
                 t = ops.wx(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
                 if c == 64 and wa.shape[0] == 64:
                     # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)

@@ -762,6 +762,23 @@ def lfa_supported(d_out, K):
     return K == 16 and d_out in (32, 64, 128, 256)
 
 
+def conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act=ACT_NONE, slope=0.0, pixel_major=False, t_point_major=False):
+    """conv1x1_gather_add_act with the 64 x 64 channel mix on split-bf16 MFMA: wpk = pack_rows64(W[64,64]) (row = output channel).
+    t f32[B,64,n], or f32[B,n,64] with t_point_major (the gathered term is then one contiguous row per pixel).  Inference only."""
+    x = _dev(x, torch.float32, "x")
+    t = _dev(t, torch.float32, "t")
+    idx = _idx32(idx, "idx")
+    B, C, m = x.shape
+    n = t.shape[1] if t_point_major else t.shape[2]
+    if C != 64 or t.shape[2 if t_point_major else 1] != 64 or wpk.numel() != 64 * 256:
+        raise ValueError("conv64_gather_add_act_mfma: built for 64 -> 64 channels, got x %s t %s" % (tuple(x.shape), tuple(t.shape)))
+    y = torch.empty((B, m, C), dtype=torch.float32, device=x.device) if pixel_major else torch.empty_like(x)
+    check(_lib.lib().gdm_conv64_gather_add_act_mfma_hip(x.data_ptr(), wpk.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
+                                                        shift.data_ptr(), B, n, m, act, float(slope), int(bool(pixel_major)),
+                                                        int(bool(t_point_major)), y.data_ptr(), _stream()), "gdm_conv64_gather_add_act_mfma_hip")
+    return y
+
+
 def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0, pixel_major=False):
     """y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]) in one pass for the 64-channel fusion
     levels.  x f32[B,64,m], wt f32[64,64] = W transposed (contiguous), t f32[B,64,n], idx int[B,m(,1)].  Inference only.

@@ -339,6 +339,12 @@ int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t*
  * y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]); wt f32[C,C] = W transposed ([ci][co]). */
 int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
                                    const float* shift, int B, int C, int n, long m, int act, float slope, float* y, void* stream);
+/* The same fusion with the K = 64 channel mix on the matrix cores (split-bf16 x3, fp32 accumulate): wpk = the 64 x 64 weight (row =
+ * output channel) packed by gdm_pack_rows64_hip; t_point_major != 0: t is f32[B, n, 64] (the gathered term is then one contiguous
+ * 256-byte row per pixel instead of 64 scattered floats); other arguments as above. */
+int gdm_conv64_gather_add_act_mfma_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
+                                       const float* shift, int B, int n, long m, int act, float slope, int pixel_major, int t_point_major,
+                                       float* y, void* stream);
 /* The same with the output layout selectable: pixel_major != 0 writes y f32[B, m, C] (one 256-byte row per pixel). */
 int gdm_conv1x1_gather_add_act2_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
                                     const float* shift, int B, int C, int n, long m, int act, float slope, int pixel_major,

@@ -513,6 +513,16 @@ def test_conv1x1_gather_add_act(ops, act):
     got_pm = ops.conv1x1_gather_add_act(x.cuda(), w.t().contiguous().cuda(), t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2,
                                         pixel_major=True).cpu()
     assert got_pm.shape == (B, m, C) and torch.equal(got_pm.transpose(1, 2), got)          # same arithmetic, other layout
+    # the same fusion with the channel mix on split-bf16 MFMA (the default in the model): both layouts, ragged m
+    wpk = ops.pack_rows64(w.cuda())
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    got_mm = ops.conv64_gather_add_act_mfma(x.cuda(), wpk, t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2).cpu()
+    assert (got_mm.double() - ref).abs().max().item() < tol
+    got_mm_pm = ops.conv64_gather_add_act_mfma(x.cuda(), wpk, t.cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2, pixel_major=True).cpu()
+    assert got_mm_pm.shape == (B, m, C) and torch.equal(got_mm_pm.transpose(1, 2), got_mm)
+    got_tpm = ops.conv64_gather_add_act_mfma(x.cuda(), wpk, t.transpose(1, 2).contiguous().cuda(), idx.cuda(), scale.cuda(), shift.cuda(), act, 0.2,
+                                             t_point_major=True).cpu()
+    assert torch.equal(got_tpm, got_mm)                              # the point term point-major: same values, one row per gathered point
 
 
 @pytest.mark.parametrize("B,H,W,N", [(2, 16, 24, 100), (1, 128, 128, 2048), (3, 9, 7, 33)])
