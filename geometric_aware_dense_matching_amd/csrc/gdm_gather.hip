@@ -140,6 +140,40 @@ __global__ __launch_bounds__(GB) void gather_max_rowlds_kernel(const float* __re
     }
 }
 
+// Few output points (the deep levels: 32 .. 128 points per crop against a 1024 .. 4096-pixel map): one thread per (channel, point),
+// so a crop's C * m outputs fill whole waves instead of m lanes walking 8 channels in sequence.
+template <int KMAX>
+__global__ __launch_bounds__(GB) void gather_max_flat_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                             int C, int n, int m, int K, float* __restrict__ out,
+                                                             int32_t* __restrict__ arg)
+{
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * GB + threadIdx.x;           // over [C, m]
+    if (e >= (long)C * m) return;
+    const int c = (int)(e / m), j = (int)(e - (long)c * m);
+    const int32_t* ip = idx + ((long)b * m + j) * K;
+    const float* f = feat + ((long)b * C + c) * n;
+    int n0 = min(max(ip[0], 0), n - 1);
+    float best = f[n0];
+    int bi = n0;
+    float v[KMAX];
+    int nb[KMAX];
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k) {
+        nb[k] = min(max(k < K ? ip[k] : ip[0], 0), n - 1);
+        v[k] = f[nb[k]];
+    }
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k) {
+        if (v[k] > best) {
+            best = v[k];
+            bi = nb[k];
+        }
+    }
+    out[((long)b * C + c) * m + j] = best;
+    if (arg) arg[((long)b * C + c) * m + j] = bi;
+}
+
 __global__ __launch_bounds__(GB) void gather_max_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ arg,
                                                             int n, long total_rows_m, int m, float* __restrict__ gfeat)
 {
@@ -406,6 +440,14 @@ extern "C" int gdm_gather_max_hip(const float* feat, const int32_t* idx, int B, 
     if (rowlds < 0) {
         const char* e = getenv("GDM_GATHER_MAX_ROWLDS");
         rowlds = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (rowlds && m < 256 && (long)C * m >= 4096) {
+        dim3 g3(gdm_cdiv((long)C * m, GB), B);
+        if (K <= 16)
+            hipLaunchKernelGGL(gather_max_flat_kernel<16>, g3, dim3(GB), 0, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+        else
+            hipLaunchKernelGGL(gather_max_flat_kernel<32>, g3, dim3(GB), 0, STREAM(stream), feat, idx, C, n, m, K, out, arg);
+        return gdm_launch_status("gather_max_flat_kernel");
     }
     if (rowlds && n >= 1024 && n <= 16384 && (long)m * K >= 2048 && C <= 65535) {
         static bool attr = false;

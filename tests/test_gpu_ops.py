@@ -148,7 +148,8 @@ def _feat_idx(rs, B, C, n, m, K):
 
 
 @pytest.mark.parametrize("B,C,n,m,K", [(2, 64, 2048, 512, 16), (1, 3, 100, 37, 5), (2, 129, 300, 300, 16), (2, 64, 4096, 128, 16),
-                                       (2, 64, 16384, 2048, 16), (1, 5, 1027, 300, 7), (1, 2, 16384, 129, 20), (1, 3, 16385, 200, 16)])
+                                       (2, 64, 16384, 2048, 16), (1, 5, 1027, 300, 7), (1, 2, 16384, 129, 20), (1, 3, 16385, 200, 16),
+                                       (2, 256, 4096, 32, 16), (1, 1024, 1024, 8, 16), (2, 200, 100, 33, 20)])
 def test_gather_max(ops, B, C, n, m, K):
     from oracle import ops_ref
     feat, idx = _feat_idx(np.random.RandomState(1), B, C, n, m, K)
