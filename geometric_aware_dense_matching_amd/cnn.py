@@ -198,7 +198,7 @@ class PSPModule(nn.Module):
             B, Cin = feats.shape[0], feats.shape[1]
             if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
                 wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
-                g = ops.gemm_bf16x3(feats.reshape(B, Cin, h * w), wpk, co).view(B, -1, h, w)
+                g = ops.gemm_bf16x3_map(feats, wpk, co)                   # reads layer4's packed output when it is there
             else:
                 g = ops.wx(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
             sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]

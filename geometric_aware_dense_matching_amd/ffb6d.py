@@ -153,7 +153,7 @@ class FFB6DEmb(nn.Module):
                     raise RuntimeError("pixel-major fusion output is the 64-channel kernel's; _sparse_final_ok() guards the caller")
                 if settings.USE_MFMA_GEMM and ops.gemm_supported(c, wa.shape[0], hr * wr):
                     wpk, co = cached_gemm_weight(fuse_layer, "wa", wa, (fuse_layer.conv.weight,))
-                    x = ops.gemm_bf16x3(rgb_emb0.reshape(bs, c, hr * wr), wpk, co)               # [B,Cout,HW], split-bf16 MFMA
+                    x = ops.gemm_bf16x3_map(rgb_emb0, wpk, co).view(bs, co, hr * wr)   # split-bf16 MFMA; reads the stage's packed output
                 else:
                     x = ops.wx(wa, rgb_emb0.reshape(bs, c, hr * wr))                    # [B,Cout,HW]
                 scale, shift = folded_bn(fuse_layer.normlayer.bn)

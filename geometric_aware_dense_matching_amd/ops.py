@@ -1054,6 +1054,16 @@ def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None,
     return (out, opk) if out_packed else out
 
 
+def gemm_bf16x3_map(x, wpk, cout):
+    """W @ x over the channels of a map x f32[B,Cin,H,W] -> f32[B,cout,H,W] on split-bf16 MFMA.  If x carries the packed operand its
+    producer wrote (`_gdm_packed`, the trunk's residual blocks), the GEMM reads that and no pack launch is needed."""
+    B, Cin, H, W = x.shape
+    xp = getattr(x, "_gdm_packed", None)
+    if isinstance(xp, PackedAct) and xp.shape == (B, Cin, H, W) and W % 32 == 0:
+        return conv1x1_packed2d(xp, wpk, cout)
+    return gemm_bf16x3(x.reshape(B, Cin, H * W), wpk, cout).view(B, cout, H, W)
+
+
 def conv1x1_packed2d(xp, wpk, cout, scale=None, shift=None, act=ACT_NONE, stride=1):
     """1x1 convolution (stride 1 or 2) of a PackedAct map with gemm_pack_weight'ed weights -> f32[B,cout,H/stride,W/stride]: the
     downsample branch of a residual block on the packed operand its 3x3 convolution already reads.  Inference only."""
