@@ -70,8 +70,10 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
 
     pyr = dict(zip(names, outs))
     for i in range(4):
-        pyr["cld_xyz%d" % i] = levels[i]
-        pyr["cld_sub_idx%d" % i] = pyr["cld_nei_idx%d" % i][:, : levels[i + 1].shape[1]]
+        # prefix views are batch-strided; every consumer (two LFA stage launches per level, the pooling gather) wants them dense,
+        # so they are made contiguous once here instead of once per use
+        pyr["cld_xyz%d" % i] = levels[i].contiguous()
+        pyr["cld_sub_idx%d" % i] = pyr["cld_nei_idx%d" % i][:, : levels[i + 1].shape[1]].contiguous()
     return pyr
 
 

@@ -301,6 +301,11 @@ def test(args):
     loader = torch.utils.data.DataLoader(make_dataset(args, "test", cls_ids=ids), batch_size=batch_size, shuffle=False, num_workers=2)
     graphs = {}
     results = []
+    # evaluator.py:308-463: when the loader carries ground-truth poses (`RT`), every instance's ADD(-S) / re / te / re-projection error
+    # is computed on the device per object group and the reference's recall table is printed at the end
+    from . import evaluation
+    table = evaluation.RecallTable()
+    sym_names = set(ds.get("sym_objs", ()))                 # config/*_cfg.py SYM_OBJS: object NAMES
     with torch.no_grad():
         for batch in loader:
             t0 = time.perf_counter()
@@ -317,6 +322,18 @@ def test(args):
             torch.cuda.synchronize()
             results.append(dict(time=time.perf_counter() - t0, cls_id=cls, count=out["mask"].sum(dim=1).cpu(), best_idx=out["best_idx"].cpu(),
                                 best_sim=out["best_sim"].cpu(), mask=out["mask"].cpu(), RT=out["RT"].cpu(), valid=out["valid"].cpu()))
+            if "RT" in cu and cu["RT"].dim() == 3:
+                Kcam = cu["K"] if "K" in cu else torch.from_numpy(synthetic.LM_K).to(device)
+                for cid in sorted(set(cls)):
+                    rows = torch.tensor([i for i, c in enumerate(cls) if c == cid], device=device)
+                    err = evaluation.pose_errors(out["RT"][rows], cu["RT"][rows][:, :3], model_dict[cid].model_emb.xyz,
+                                                 Kcam[rows] if Kcam.dim() == 3 else Kcam, symmetric=obj_name_of(ds, cid) in sym_names,
+                                                 sym_rots=getattr(model_dict[cid].model_emb, "sym_rots", None))
+                    table.update(obj_name_of(ds, cid), err, ds["diameters"][cid] / 1000.0)
+    if table.recalls:
+        test.last_table = table
+        if args.local_rank == 0:
+            print(table.format())
     return results
 
 

@@ -82,3 +82,13 @@ def pose_inputs(B=3, N=600, M=500, seed=17):
         cld[b, :3] = pts.T
         cld[b, 3:] = rs.rand(6, N)
     return dict(model=model, idx=idx, mask=mask, cld=cld, RT=RT)
+
+
+def sym_rotations():
+    """A discrete symmetry group as evaluator.py's sym_infos hold it (K x 3 x 3, model to model): identity and the three half turns."""
+    out = [np.eye(3)]
+    for ax in range(3):
+        d = -np.ones(3)
+        d[ax] = 1.0
+        out.append(np.diag(d))
+    return np.stack(out)

@@ -461,7 +461,31 @@ def main():
         poses.append(T)
         adds.append(env["add"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
         adis.append(env["adi"](T[:, :3], T[:, 3], pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64), pi["model"].astype(np.float64)))
-    np.savez_compressed(os.path.join(HERE, "pose.npz"), RT=np.stack(poses), add=np.array(adds), adi=np.array(adis))
+    # rotation / translation / re-projection errors and the closest symmetric ground truth (pose_error.py:400-445,277-294,
+    # pose_utils.py:430-454), again from the reference's own text, on the same estimated / ground-truth poses
+    exec(grab("lib/pysixd/pose_error.py", "re("), env)
+    exec(grab("lib/pysixd/pose_error.py", "te("), env)
+    exec(grab("lib/pysixd/pose_error.py", "transform_pts_Rt_2d("), env)
+    exec(grab("lib/pysixd/pose_error.py", "arp_2d("), env)
+    import torch as _torch
+    env["torch"] = _torch
+    exec(grab("utils/pose_utils.py", "get_closest_rot("), env)
+    from geometric_aware_dense_matching_amd.synthetic import LM_K
+    sym = gin.sym_rotations()
+    res_, tes_, projs_, re_sym_, proj_sym_ = [], [], [], [], []
+    for b in range(pi["idx"].shape[0]):
+        T = poses[b]
+        Rg, tg = pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64)
+        res_.append(env["re"](T[:, :3], Rg))
+        tes_.append(env["te"](T[:, 3], tg))
+        projs_.append(env["arp_2d"](T[:, :3], T[:, 3], Rg, tg, pi["model"].astype(np.float64), LM_K.astype(np.float64)))
+        # a symmetric object: the ground truth seen through another element of the symmetry group
+        Rg2 = Rg.dot(sym[1 + b % (sym.shape[0] - 1)])
+        Rc = env["get_closest_rot"](T[:, :3], Rg2, sym)
+        re_sym_.append(env["re"](T[:, :3], Rc))
+        proj_sym_.append(env["arp_2d"](T[:, :3], T[:, 3], Rc, tg, pi["model"].astype(np.float64), LM_K.astype(np.float64)))
+    np.savez_compressed(os.path.join(HERE, "pose.npz"), RT=np.stack(poses), add=np.array(adds), adi=np.array(adis), re=np.array(res_),
+                        te=np.array(tes_), proj=np.array(projs_), re_sym=np.array(re_sym_), proj_sym=np.array(proj_sym_))
     # ------------------------------------------------------------------ dataset configurations the entry points select by -dataset_name
     import importlib
     cfgs = {}

@@ -1,0 +1,39 @@
+"""CPU: the oracle's restatement of the reference's pose errors (oracle/eval_ref.py) against the vectors tests/golden/make_golden.py
+produced by executing pose_error.py's re / te / arp_2d and pose_utils.py's get_closest_rot from the reference's own text."""
+import os
+
+import numpy as np
+
+from oracle import eval_ref
+from tests.golden import inputs as gin
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_re_te_arp2d_and_closest_symmetric_rotation_vs_reference_golden():
+    from geometric_aware_dense_matching_amd.synthetic import LM_K
+    g = np.load(os.path.join(G, "pose.npz"))
+    pi = gin.pose_inputs()
+    sym = gin.sym_rotations()
+    K = LM_K.astype(np.float64)
+    pts = pi["model"].astype(np.float64)
+    for b in range(pi["idx"].shape[0]):
+        T = g["RT"][b]
+        Rg, tg = pi["RT"][b, :, :3].astype(np.float64), pi["RT"][b, :, 3].astype(np.float64)
+        assert abs(eval_ref.re(T[:, :3], Rg) - g["re"][b]) < 1e-9
+        assert abs(eval_ref.te(T[:, 3], tg) - g["te"][b]) < 1e-12 * max(1.0, g["te"][b])
+        assert abs(eval_ref.arp_2d(T[:, :3], T[:, 3], Rg, tg, pts, K) - g["proj"][b]) < 1e-9 * max(1.0, g["proj"][b])
+        Rg2 = Rg.dot(sym[1 + b % (sym.shape[0] - 1)])
+        Rc = eval_ref.get_closest_rot(T[:, :3], Rg2, sym)
+        assert abs(eval_ref.re(T[:, :3], Rc) - g["re_sym"][b]) < 1e-9
+        assert abs(eval_ref.arp_2d(T[:, :3], T[:, 3], Rc, tg, pts, K) - g["proj_sym"][b]) < 1e-9 * max(1.0, g["proj_sym"][b])
+
+
+def test_recall_flags_and_table_shape():
+    f = eval_ref.recall_flags(0.004, 1.5, 0.01, 1.0, 0.1)
+    assert list(f) == eval_ref.METRICS and f["ad_5"] == 1.0 and f["ad_2"] == 0.0 and f["rete_2"] == 1.0 and f["proj_2"] == 1.0
+    rec = {"ape": {m: [1.0, 0.0] for m in eval_ref.METRICS}, "cat": {m: [] for m in eval_ref.METRICS}}
+    err = {"ape": {"re": [1.0, 3.0], "te": [0.01, 0.03]}, "cat": {"re": [], "te": []}}
+    tab = eval_ref.table(rec, err)
+    assert tab[0] == ["objects", "ape", "cat", "Avg(2)"] and tab[1] == ["ad_2", "50.00", 0.0, "25.00"] and len(tab) == 1 + 16 + 2
+    assert tab[-2][:2] == ["re", "2.00"] and np.isnan(tab[-2][2])
