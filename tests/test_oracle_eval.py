@@ -37,3 +37,36 @@ def test_recall_flags_and_table_shape():
     tab = eval_ref.table(rec, err)
     assert tab[0] == ["objects", "ape", "cat", "Avg(2)"] and tab[1] == ["ad_2", "50.00", 0.0, "25.00"] and len(tab) == 1 + 16 + 2
     assert tab[-2][:2] == ["re", "2.00"] and np.isnan(tab[-2][2])
+
+
+def test_product_recall_table_on_host_arrays_equals_the_oracle_table():
+    """evaluation.RecallTable is host-side bookkeeping: fed with numpy errors it must reproduce oracle/eval_ref.table (the restatement of
+    /root/reference/evaluator.py:408-463) string for string, ground truths without a prediction included."""
+    from geometric_aware_dense_matching_amd import evaluation
+    assert evaluation.METRICS == eval_ref.METRICS
+    rs = np.random.RandomState(2)
+    tab = evaluation.RecallTable()
+    rec, err = {}, {}
+    for name, diam, n in (("ape", 0.102, 23), ("can", 0.201, 11), ("eggbox", 0.165, 1)):
+        e = dict(ad=np.abs(rs.randn(n)) * 0.02, re=np.abs(rs.randn(n)) * 6, te=np.abs(rs.randn(n)) * 0.06, proj=np.abs(rs.randn(n)) * 6)
+        tab.update(name, e, diam)
+        rec[name] = {m: [] for m in eval_ref.METRICS}
+        err[name] = {"re": e["re"].tolist(), "te": e["te"].tolist()}
+        for i in range(n):
+            for m, v in eval_ref.recall_flags(e["ad"][i], e["re"][i], e["te"][i], e["proj"][i], diam).items():
+                rec[name][m].append(v)
+    tab.missing("can", 3)
+    for m in eval_ref.METRICS:
+        rec["can"][m] += [0.0] * 3
+    assert tab.table() == eval_ref.table(rec, err)
+    assert len(tab.format().splitlines()) == 19
+
+
+def test_settings_switch_lists_are_consistent():
+    from geometric_aware_dense_matching_amd import settings
+    for name in settings.ALL_SWITCHES + settings.SPLIT_BF16_SWITCHES:
+        assert isinstance(getattr(settings, name), bool), name
+    assert set(settings.SPLIT_BF16_SWITCHES) <= set(settings.ALL_SWITCHES)
+    doc = settings.__doc__
+    for name in settings.ALL_SWITCHES:
+        assert name in doc, "settings.py's table does not describe %s" % name
