@@ -54,5 +54,60 @@ for it in range(16):
         settings.USE_FUSED_LFA = False; ref = blk(xyz, feat, idx)
         settings.USE_FUSED_LFA = True; got = blk(xyz, feat, idx)
     chk("lfa", (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (d_out, n, B))
+# gather_max: every dispatch form (LDS-staged rows, thread per (channel, point), point per thread)
+for it in range(40):
+    B, C, n, m, K = rs.randint(1, 4), rs.randint(1, 300), int(rs.choice([7, 100, 1024, 1500, 4096, 16384, 17000])), rs.randint(1, 700), int(rs.choice([1, 5, 16, 20]))
+    feat = torch.randn(B, C, n, device="cuda"); idx = torch.randint(0, n, (B, m, K), device="cuda", dtype=torch.int32)
+    got = ops.gather_max(feat, idx)
+    ref = torch.gather(feat[:, :, None, :].expand(B, C, m, n), 3, idx.long()[:, None].expand(B, C, m, K)).max(dim=3)[0] if C * m * n < 3e8 else None
+    if ref is not None:
+        chk("gather_max", torch.equal(got, ref), (B, C, n, m, K))
+# strided / plain 3x3 and 1x1 on one packed operand
+for it in range(12):
+    B, Cin, Cout, Ho, Wo = rs.randint(1, 3), int(rs.choice([64, 128, 256])), int(rs.choice([64, 128, 200, 256])), rs.randint(1, 20), 32 * rs.randint(1, 3)
+    if Cout % 8: continue
+    x = torch.randn(B, Cin, 2 * Ho, 2 * Wo, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5
+    xp = ops.conv3x3_pack_act(x)
+    got = ops.conv3x3_bf16x3(xp, ops.conv3x3_pack_weight(w), Cout, stride=2)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=1)
+    chk("conv3x3 s2", (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (B, Cin, Cout, Ho, Wo))
+    if ops.gemm_supported(Cin, Cout, 64):
+        w1 = torch.randn(Cout, Cin, device="cuda") / Cin ** 0.5
+        got1 = ops.conv1x1_packed2d(xp, ops.gemm_pack_weight(w1), Cout, stride=2)
+        ref1 = torch.nn.functional.conv2d(x.double(), w1.double()[:, :, None, None], stride=2)
+        chk("conv1x1 s2", (got1.double() - ref1).abs().max().item() < 3e-5 * max(1.0, ref1.abs().max().item()), (B, Cin, Cout, Ho, Wo))
+# the sampled-pixel final stage and the per-point heads at ragged sizes
+for it in range(12):
+    B, H, W, N = rs.randint(1, 4), rs.randint(2, 40), rs.randint(2, 40), rs.randint(1, 300)
+    x = torch.randn(B, 64, H, W, device="cuda"); w3 = torch.randn(64, 64, 3, 3, device="cuda") * 0.05; wf = torch.randn(64, 64, device="cuda") / 8
+    sc = torch.rand(64, device="cuda") + 0.5; sh = torch.randn(64, device="cuda"); bf = torch.randn(64, device="cuda")
+    ch = torch.randint(0, 4 * H * W, (B, N), device="cuda", dtype=torch.int32)
+    up = torch.nn.functional.interpolate(x.double(), size=(2 * H, 2 * W), mode="bilinear", align_corners=True)
+    h = torch.nn.functional.conv2d(up, w3.double(), padding=1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    h = torch.where(h > 0, h, 0.25 * h)
+    ref = torch.log_softmax(torch.einsum("oc,bchw->bohw", wf.double(), h) + bf.double()[None, :, None, None], dim=1).reshape(B, 64, -1)
+    ref = torch.gather(ref, 2, ch.long()[:, None, :].expand(B, 64, N))
+    got = ops.upconv_final_points(x.reshape(B, 64, H * W).transpose(1, 2).contiguous(), (H, W), ch, ops.upconv_fused64_pack_weight(w3), sc, sh, 2, 0.25,
+                                  ops.pack_rows64(wf), bf, (2 * H, 2 * W))
+    chk("final_points", (got.double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item()), (B, H, W, N))
+for it in range(8):
+    B, N, Ca = rs.randint(1, 4), rs.randint(1, 400), int(rs.choice([8, 64, 120, 128]))
+    x0 = torch.randn(B, 128, N, device="cuda")
+    Ws = [torch.randn(128, 128, device="cuda") / 11 for _ in range(8)]
+    scs = [torch.rand(128, device="cuda") + 0.5 for _ in range(8)]; shs = [torch.randn(128, device="cuda") * 0.3 for _ in range(8)]
+    acts = [1, 1, 1, 0, 1, 1, 1, 1]
+    wl = torch.randn(2, 128, device="cuda") / 11; bl = torch.randn(2, device="cuda")
+    xx = x0.double(); feat = None
+    for l in range(8):
+        y = torch.einsum("oc,bcn->bon", Ws[l].double(), xx) * scs[l].double()[None, :, None] + shs[l].double()[None, :, None]
+        if l == 3: feat = y
+        if acts[l]: y = y.clamp(min=0)
+        if l == 4: y = x0.double() + y
+        xx = y
+    seg = torch.einsum("oc,bcn->bon", wl.double(), xx) + bl.double()[None, :, None]
+    layers = [(ops.gemm_pack_weight(Ws[l]), scs[l], shs[l], acts[l]) for l in range(8)]
+    gf, gs = ops.point_heads(x0[:, :Ca].contiguous(), x0[:, Ca:].contiguous() if Ca < 128 else None, layers, (ops.gemm_pack_weight(wl), bl, 2), 3, 4)
+    chk("heads", (gf.double() - feat).abs().max().item() < 5e-5 * max(1.0, feat.abs().max().item())
+        and (gs.double() - seg).abs().max().item() < 1e-4 * max(1.0, seg.abs().max().item()), (B, N, Ca))
 torch.cuda.synchronize()
 print("fuzz done, mismatches:", bad)
