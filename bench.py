@@ -52,7 +52,8 @@ def parse():
                          "(default: split-bf16 MFMA, hi*hi+hi*lo+lo*hi with fp32 accumulation, |err| <= 3*2^-18 per product)")
     ap.add_argument("--cpu-crops", type=int, default=96, help="crops in the bounded CPU sample (~10-20 s of host work)")
     ap.add_argument("--eager", action="store_true", help="time the eager step loop instead of hipGraph replays")
-    ap.add_argument("--no-extras", action="store_true", help="skip the batch-32 / exact-f32 / DGCNN / training / per-kernel roofline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-32 / mesh-cached / per-kernel roofline legs (and the heavy ones)")
+    ap.add_argument("--no-heavy-extras", action="store_true", help="skip the legs that run after the JSON line (exact-f32, DGCNN, training step)")
     return ap.parse_args()
 
 
@@ -215,11 +216,55 @@ def kernel_rooflines(torch, dev, B, N):
     return out
 
 
-def extra_legs(torch, dev, args, model, N, M):
-    """Driver-visible figures beyond the headline (1-GPU runs only): batch 32 (north_star quotes its end-to-end target there),
-    strict-fp32 arithmetic, the geoMatch_DGCNN variant (BASELINE config 4) and one training step (config 3's per-GPU work)."""
-    import numpy as np
-    from geometric_aware_dense_matching_amd import infer, matching, ops, pyramid, settings, synthetic, train_lm
+def _leg(out, name, fn):
+    """Run one extras leg; an exception becomes {"error": "..."} under its name instead of ending the run."""
+    try:
+        fn()
+    except Exception as e:                                   # noqa: BLE001 -- an extras leg must never cost the headline
+        out[name] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+
+
+def light_extras(torch, dev, args, model, N, M):
+    """Driver-visible figures that ride in the JSON line (1-GPU runs only; a few seconds in all): batch 32 (north_star quotes its
+    end-to-end target there) and the deployment form with the mesh descriptors cached per object."""
+    from geometric_aware_dense_matching_amd import infer, synthetic
+    out = {}
+    prec = "bf16x3" if args.precision == "bf16x3" else "f32"
+
+    def dev_batch(seed, B):
+        b = synthetic.make_batch(seed=seed, batch=B, n_points=N)
+        return {k: torch.from_numpy(b[k]).to(dev) for k in ("rgb", "cld_rgb_nrm", "choose", "dpt_xyz")}
+
+    def b32():
+        # ---- batch 32, hipGraph replay (pyramid + forward + matching)
+        gp = infer.GraphedPipeline(model, dev_batch(300, 32), precision=prec, with_pose=False)
+        ms = timed(gp.graph.replay, 10, torch)
+        out["b32"] = {"crops_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "hipGraph replay"}
+
+    def mesh_cached():
+        # ---- the deployment form: the object's mesh descriptors depend on the weights only, so a server computes them once per object
+        # (GeoMatch(cache_mesh_in_eval=True)); the headline keeps recomputing them every step, as the reference's forward does
+        if getattr(model, "cache_mesh_in_eval", False):
+            return
+        model.cache_mesh_in_eval = True
+        try:
+            gp = infer.GraphedPipeline(model, dev_batch(302, args.batch), precision=prec, with_pose=False)
+            ms = timed(gp.graph.replay, 10, torch)
+            out["mesh_cached"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "batch": args.batch,
+                                  "launch": "hipGraph replay", "what": "mesh branch computed once per object instead of once per step"}
+        finally:
+            model.cache_mesh_in_eval = False
+            model._mesh_cache = None
+
+    _leg(out, "b32", b32)
+    _leg(out, "mesh_cached", mesh_cached)
+    return out
+
+
+def heavy_extras(torch, dev, args, model, N, M):
+    """Further legs, run AFTER the JSON line is on stdout (strict-fp32 arithmetic, the geoMatch_DGCNN variant = BASELINE config 4,
+    one training step = config 3's per-GPU work); they go to stderr and gpurun_out/bench_extras.json, each guarded on its own."""
+    from geometric_aware_dense_matching_amd import matching, pyramid, settings, synthetic, train_lm
     from geometric_aware_dense_matching_amd.config import make_model_cfg
     from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
     out = {}
@@ -229,28 +274,10 @@ def extra_legs(torch, dev, args, model, N, M):
         b = synthetic.make_batch(seed=seed, batch=B, n_points=N)
         return {k: torch.from_numpy(b[k]).to(dev) for k in ("rgb", "cld_rgb_nrm", "choose", "dpt_xyz")}
 
-    # ---- batch 32, hipGraph replay (pyramid + forward + matching)
-    gp = infer.GraphedPipeline(model, dev_batch(300, 32), precision=prec, with_pose=False)
-    ms = timed(gp.graph.replay, 10, torch)
-    out["b32"] = {"crops_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "hipGraph replay"}
-    del gp
-
-    # ---- the deployment form: the object's mesh descriptors depend on the weights only, so a server computes them once per object
-    # (GeoMatch(cache_mesh_in_eval=True)); the headline keeps recomputing them every step, as the reference's forward does
-    if not getattr(model, "cache_mesh_in_eval", False):
-        model.cache_mesh_in_eval = True
-        try:
-            gp = infer.GraphedPipeline(model, dev_batch(302, args.batch), precision=prec, with_pose=False)
-            ms = timed(gp.graph.replay, 10, torch)
-            out["mesh_cached"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "batch": args.batch,
-                                  "launch": "hipGraph replay", "what": "mesh branch computed once per object instead of once per step"}
-            del gp
-        finally:
-            model.cache_mesh_in_eval = False
-            model._mesh_cache = None
-
-    # ---- strict fp32: f32-MFMA matching, trunk convolutions / GEMMs back on MIOpen / hipBLASLt (no split-bf16 anywhere), eager
-    if not args.exact_f32:
+    def exact_f32():
+        # ---- strict fp32: f32-MFMA matching, trunk convolutions / GEMMs back on MIOpen / hipBLASLt (no split-bf16 anywhere), eager
+        if args.exact_f32:
+            return
         saved = tuple(getattr(settings, n) for n in settings.SPLIT_BF16_SWITCHES)
         for n in settings.SPLIT_BF16_SWITCHES:
             setattr(settings, n, False)
@@ -272,70 +299,89 @@ def extra_legs(torch, dev, args, model, N, M):
             for n, v in zip(settings.SPLIT_BF16_SWITCHES, saved):
                 setattr(settings, n, v)
 
-    # ---- geoMatch_DGCNN variant: eval forward + matching at the same shape
-    from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
-    dg = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=M), 1,
-                       model_points=synthetic.make_model_points(1, M)).to(dev).eval()
-    d = dev_batch(302, args.batch)
+    def dgcnn():
+        # ---- geoMatch_DGCNN variant: eval forward + matching at the same shape
+        from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
+        dg = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=M), 1,
+                           model_points=synthetic.make_model_points(1, M)).to(dev).eval()
+        d = dev_batch(302, args.batch)
 
-    def dg_step():
-        return matching.match_frames(dg(d), precision=prec)
-    with torch.no_grad():
-        for _ in range(3):
-            dg_step()
-        torch.cuda.synchronize()
-        ms = timed(dg_step, 5, torch)
-    out["dgcnn"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager", "batch": args.batch,
-                    "config": "geoMatch_DGCNN (k=16 for both trunks, as its cfg gives), N=%d x M=%d, fwd + matching" % (N, M)}
-    del dg
+        def dg_step():
+            return matching.match_frames(dg(d), precision=prec)
+        with torch.no_grad():
+            for _ in range(3):
+                dg_step()
+            torch.cuda.synchronize()
+            ms = timed(dg_step, 5, torch)
+        out["dgcnn"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "eager", "batch": args.batch,
+                        "config": "geoMatch_DGCNN (k=16 for both trunks, as its cfg gives), N=%d x M=%d, fwd + matching" % (N, M)}
 
-    # ---- one training step (fwd + fused matching loss + bwd + Adam) at the reference's default training shape
-    Bt, Nt, Mt = 24, 4096, 4096                                   # config/lmo_cfg.py:95-98,119
-    find = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = False                        # MIOpen default algorithms: find mode over ~100 backward shapes takes minutes
-    try:
-        tm = GeoMatch(make_model_cfg(n_mesh_node=Mt, num_points=Nt), 1, model_points=synthetic.make_model_points(1, Mt)).to(dev).train()
-        opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
-        ds = train_lm.SyntheticCrops(Bt, Nt, Mt, seed=0)
-        cu = train_lm.to_device(torch.utils.data.default_collate([ds[i] for i in range(Bt)]), dev)
+    def train():
+        # ---- one training step (fwd + fused matching loss + bwd + Adam) at the reference's default training shape
+        Bt, Nt, Mt = 24, 4096, 4096                                   # config/lmo_cfg.py:95-98,119
+        find = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = False                        # MIOpen default algorithms: find mode over ~100 backward shapes takes minutes
+        try:
+            tm = GeoMatch(make_model_cfg(n_mesh_node=Mt, num_points=Nt), 1, model_points=synthetic.make_model_points(1, Mt)).to(dev).train()
+            opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
+            ds = train_lm.SyntheticCrops(Bt, Nt, Mt, seed=0)
+            cu = train_lm.to_device(torch.utils.data.default_collate([ds[i] for i in range(Bt)]), dev)
 
-        def train_step():
-            o, _ = train_lm.model_fn_dec(tm, cu, dev)
-            o["loss"].backward()
-            opt.step()
-            opt.zero_grad()
-        for _ in range(2):
-            train_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            train_step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
-        out["train"] = {"train_ms_per_step": round(ms, 2), "crops_per_s": round(Bt / ms * 1e3, 1), "batch": Bt, "n_points": Nt, "n_model": Mt,
-                        "what": "fwd + losses + bwd + Adam on one GPU (per-GPU work of config 3 without the RCCL all-reduce)"}
-        # the same iteration as ONE hipGraph launch (train_graph.GraphedTrainStep): the host enqueues 1 launch instead of ~1 900
-        from geometric_aware_dense_matching_amd.train_graph import GraphedTrainStep
-        gs = GraphedTrainStep(tm, opt, dev, warmup=1)            # batch already on the device, as in the eager leg above
-        for _ in range(3):
-            gs.step(cu)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            gs.step(cu)
-        t_host = (time.perf_counter() - t0) / 3 * 1e3
-        torch.cuda.synchronize()
-        msg = (time.perf_counter() - t0) / 3 * 1e3
-        out["train"].update(graphed_ms_per_step=round(msg, 2), graphed_host_ms_per_step=round(t_host, 2), graphed_launches_per_step=1)
-        del tm, opt, gs
-    finally:
-        torch.backends.cudnn.benchmark = find
-    torch.cuda.empty_cache()
+            def train_step():
+                o, _ = train_lm.model_fn_dec(tm, cu, dev)
+                o["loss"].backward()
+                opt.step()
+                opt.zero_grad()
+            for _ in range(2):
+                train_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                train_step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            out["train"] = {"train_ms_per_step": round(ms, 2), "crops_per_s": round(Bt / ms * 1e3, 1), "batch": Bt, "n_points": Nt, "n_model": Mt,
+                            "what": "fwd + losses + bwd + Adam on one GPU (per-GPU work of config 3 without the RCCL all-reduce)"}
+        finally:
+            torch.backends.cudnn.benchmark = find
+
+    _leg(out, "exact_f32", exact_f32)
+    _leg(out, "dgcnn", dgcnn)
+    _leg(out, "train", train)
+    return out
+
+
+def graph_check(torch, ref, got, ref2=None, tol=1e-4):
+    """Recorded comparison of a hipGraph replay with the eager step (and of two eager steps, as the control): nothing is
+    asserted here.  `ok` is north_star's parity rule between the two launch forms: every neighbour index identical, arg-max
+    indices identical except at near-ties (the two candidates' similarities within `tol`), maxima and descriptors within `tol`."""
+    def cmp(a, b):
+        pyr_keys = [k for k in a if k.startswith("cld_") or "_nei_idx" in k]
+        bi_a, bi_b, bs_a, bs_b = a["best_idx"], b["best_idx"], a["best_sim"], b["best_sim"]
+        diff = bi_a != bi_b
+        n_idx = int(diff.sum())
+        tie_gap = float((bs_a[diff].double() - bs_b[diff].double()).abs().max()) if n_idx else 0.0
+        r = {"idx_equal": n_idx == 0, "n_idx_diff": n_idx, "idx_diff_max_sim_gap": tie_gap,
+             "max_abs_sim_diff": float((bs_a.double() - bs_b.double()).abs().max()),
+             "pyramid_equal": all(torch.equal(a[k], b[k]) for k in pyr_keys), "n_pyramid_arrays": len(pyr_keys),
+             "rgbd_max_abs_diff": float((a["rgbd"].double() - b["rgbd"].double()).abs().max()),
+             "seg_max_abs_diff": float((a["seg"].double() - b["seg"].double()).abs().max()),
+             "mask_equal": bool(torch.equal(a["mask"], b["mask"]))}
+        r["bit_identical"] = bool(r["idx_equal"] and r["pyramid_equal"] and r["mask_equal"] and r["max_abs_sim_diff"] == 0.0
+                                  and r["rgbd_max_abs_diff"] == 0.0 and r["seg_max_abs_diff"] == 0.0)
+        r["ok"] = bool(r["pyramid_equal"] and r["max_abs_sim_diff"] <= tol and r["rgbd_max_abs_diff"] <= tol and tie_gap <= tol)
+        return r
+    out = cmp(ref, got)
+    if ref2 is not None:
+        c = cmp(ref, ref2)
+        out["eager_vs_eager"] = {k: c[k] for k in ("bit_identical", "n_idx_diff", "max_abs_sim_diff", "rgbd_max_abs_diff", "pyramid_equal")}
+    out["tolerance"] = tol
     return out
 
 
 def main():
     args = parse()
+    t_start = time.perf_counter()
     if args.exact_f32:                      # read by the package at import time
         for env in ("GDM_MFMA_CONV", "GDM_MFMA_GEMM", "GDM_FUSED_UPCONV", "GDM_SPARSE_FINAL", "GDM_FUSED_HEADS", "GDM_MFMA_STRIDED"):
             os.environ[env] = "0"              # every split-bf16 product path off (settings.SPLIT_BF16_SWITCHES)
@@ -343,7 +389,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from geometric_aware_dense_matching_amd import matching, ops, pyramid, synthetic
+    from geometric_aware_dense_matching_amd import _lib, ops, pyramid, settings, synthetic
     from geometric_aware_dense_matching_amd.config import make_model_cfg
     from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
 
@@ -360,7 +406,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv kernels during warmup
+    # MIOpen find mode picks algorithms by TIMING them on the box at hand, i.e. it may pick differently from one box to the next; the
+    # step's library calls use the libraries' default (deterministic, input-independent) choices instead
+    torch.backends.cudnn.benchmark = False
 
     B, N, M = args.batch, args.npoints, args.mesh
     torch.manual_seed(0)
@@ -380,29 +428,33 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_ev = []
+    step_pool = ops.BufferPool()               # the step's scratch buffers: owned here, shared by the eager and the captured form
 
     def step(record=False):
-        if record:
-            e = [ev() for _ in range(5)]
-            e[0].record()
-        pyr = pyramid.build_pyramid(cld, dpt_xyz, overlap=not record)   # beside the image trunk's first stages (the instrumented
-        if record:                                                        # steps keep it on the main stream to time it)
-            e[1].record()
-        d = dict(inputs)
-        d.update(pyr)
-        ep = model(d)
-        if record:
-            e[2].record()
-        mask, count = ops.seg_mask(ep["seg"])
-        srows = ops.match_pack(ep["rgbd"], prec)
-        mrows = ops.match_pack(ep["mesh"][0], prec)
-        if record:
-            e[3].record()
-        bi, bs = ops.match_packed(srows, mrows, B, N, M, prec)
-        if record:
-            e[4].record()
-            stage_ev.append(e)
-        return bi, bs, mask
+        with ops.buffer_pool(step_pool):
+            if record:
+                e = [ev() for _ in range(5)]
+                e[0].record()
+            pyr = pyramid.build_pyramid(cld, dpt_xyz, overlap=not record)   # overlap only acts with GDM_SIDE_STREAMS=1 (default off)
+            if record:
+                e[1].record()
+            d = dict(inputs)
+            d.update(pyr)
+            ep = model(d)
+            if record:
+                e[2].record()
+            mask, count = ops.seg_mask(ep["seg"])
+            srows = ops.match_pack(ep["rgbd"], prec)
+            mrows = ops.match_pack(ep["mesh"][0], prec)
+            if record:
+                e[3].record()
+            bi, bs = ops.match_packed(srows, mrows, B, N, M, prec)
+            if record:
+                e[4].record()
+                stage_ev.append(e)
+        out = {k: v for k, v in pyr.items() if torch.is_tensor(v)}
+        out.update(best_idx=bi, best_sim=bs, mask=mask, rgbd=ep["rgbd"], seg=ep["seg"])
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -411,44 +463,59 @@ def main():
             torch.cuda.synchronize()
 
     graph = None
+    check = None
+    launch = "eager (one host call per kernel)"
     with torch.no_grad():
-        # warm-up = MIOpen find mode for the few convolutions that stay on MIOpen (stem, layer1/2) + the per-module caches.  With
-        # several ranks on one node, rank 0 goes first and fills MIOpen's user database; the others then start from it instead of
-        # all N benchmarking the same shapes (and locking the same file) at once
+        # warm-up fills the per-module caches (folded BatchNorms, packed weights) and brings the allocator to its steady state.  With
+        # several ranks on one node, rank 0 goes first (any library that keeps a per-user database fills it once, not N times at once)
         if world > 1 and rank != 0:
             dist.barrier()
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
         if world > 1 and rank == 0:
             dist.barrier()
         sync_all()
         if not args.eager:
-            # one capture of the whole step on the resident inputs (after the eager warm-up above: MIOpen has picked its kernels,
-            # the per-module caches are filled); every timed step below is one replay = the same kernels, one host call
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                graph_out = step()
-            graph.replay()
-            sync_all()
-            ref = step()
-            sync_all()
-            assert torch.equal(graph_out[0], ref[0]) and torch.equal(graph_out[1], ref[1]), "graph replay != eager step"
+            # one capture of the whole step on the resident inputs (after the eager warm-up above); every timed step below is one
+            # replay = the same kernels, one host call.  The replay is CHECKED against the eager step, and the result recorded
+            # (graph_check); a replay outside north_star's tolerance is not timed -- the eager loop is, and the run exits non-zero
+            ref = {k: v.clone() for k, v in step().items()}
+            torch.cuda.synchronize()
+            ref2 = {k: v.clone() for k, v in step().items()}
+            torch.cuda.synchronize()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    graph_out = step()
+                graph.replay()
+                graph.replay()                                 # twice: the second replay also reads what the first one left behind
+                torch.cuda.synchronize()
+                check = graph_check(torch, ref, graph_out, ref2)
+            except Exception as e:                             # noqa: BLE001 -- a failed capture must not cost the measurement
+                check = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+                torch.cuda.synchronize()
+            if check.get("ok"):
+                launch = "hipGraph replay of the whole step (one host call per step)"
+            else:
+                graph = None
+                launch = "eager (the hipGraph replay failed its check: see graph_check)"
+            del ref, ref2
+        sync_all()
         run_step = graph.replay if graph is not None else step
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run_step()
         sync_all()
         dt = time.perf_counter() - t0
-        # the other launch form, for the record (rank 0 extras): eager loop when the headline is the graph, and vice versa
+        # the other launch form, for the record: the eager loop
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
         dt_enqueue = time.perf_counter() - t1                      # host time to issue the eager steps (no wait for the GPU)
         sync_all()
         dt_eager = time.perf_counter() - t1
-        # stage breakdown from a few more, instrumented, eager steps OUTSIDE the timed region: five event records per step cost
-        # ~1 % of the step (marker packets drain the queue between kernels)
+        # stage breakdown from a few more, instrumented, eager steps OUTSIDE the timed region
         for _ in range(min(args.steps, 5)):
             step(record=True)
         sync_all()
@@ -456,107 +523,149 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank's check rides along: one rank outside tolerance is reported, it does not stop the others
+        flag = torch.tensor([0.0 if (check is None or check.get("ok")) else 1.0], dtype=torch.float64,
+                            device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        if check is not None:
+            check["ranks_outside_tolerance"] = int(flag.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
     stages = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in stage_ev])   # ms
     pyr_ms, fwd_ms, pack_ms, match_ms = stages.mean(axis=0).tolist()
 
-    # ---- roofline of the N x M descriptor kernel (SURVEY.md 8d) -------------------------------------
-    flops = 2.0 * B * N * M * 128
-    fused_bytes = 4.0 * 128 * (B * N + M) + 8.0 * B * N
-    mat_bytes = 4.0 * 128 * (B * N + M) + 4.0 * B * N * M
-    peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16x3" else MFMA_F32_PEAK_TFLOPS
-    mfma_flops = flops * (3.0 if args.precision == "bf16x3" else 1.0)    # executed MFMA work: hi*hi + hi*lo + lo*hi
-    _ = fused_bytes
-    mat_ms = fused_ms = float("nan")
-    with torch.no_grad():
-        d = dict(inputs)
-        d.update(pyramid.build_pyramid(cld, dpt_xyz))
-        ep = model(d)
-        srows = ops.match_pack(ep["rgbd"], prec)
-        mrows = ops.match_pack(ep["mesh"][0], prec)
-        sim = torch.empty((B, N, M), dtype=torch.float32, device=dev) if rank == 0 else None
-        for _ in range(3 if rank == 0 else 0):
-            ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
-        torch.cuda.synchronize()
-        # ONE event pair around K back-to-back launches (each = the N x M kernel + the 4-us split merge): an event pair per launch adds
-        # ~20 us of marker handling to every sample, which is 8 % of this kernel and made the figure disagree with rocprofv3's
-        # per-kernel durations (profiles/r01_steady_state_b16.csv, "roofline loop" line)
-        n_launch = max(args.steps, 10) if rank == 0 else 0
-        if n_launch:
-            a, b = ev(), ev()
-            a.record()
-            for _ in range(n_launch):
-                ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
-            b.record()
-            torch.cuda.synchronize()
-            mat_ms = a.elapsed_time(b) / n_launch
-            a, b = ev(), ev()
-            a.record()
-            for _ in range(n_launch):
-                ops.match_packed(srows, mrows, B, N, M, prec)
-            b.record()
-            torch.cuda.synchronize()
-            fused_ms = a.elapsed_time(b) / n_launch
-        del sim
-    roofline_fused = {"kernel": "match_kernel<fused arg-max> (+ split merge), back-to-back launches as the one the step issues", "bound": "mfma",
-                      "achieved": round(mfma_flops / (fused_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                      "frac": round(mfma_flops / (fused_ms * 1e-3) / 1e12 / peak_tf, 4),
-                      "algorithmic_tflops": round(flops / (fused_ms * 1e-3) / 1e12, 2),
-                      "avg_ms": round(fused_ms, 4), "traffic": None}
-    # PMC traffic comes from separate rocprofv3 --pmc passes (profiles/match_traffic.json), valid for the
-    # headline shape only
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "match_traffic.json")
-    if os.path.exists(tfile) and (B, N, M, args.precision) == (16, 2048, 8192, "bf16x3"):
-        try:
-            tj = json.load(open(tfile))
-            traffic = tj.get("materialised_bytes_per_launch")
-            roofline_fused["traffic"] = tj.get("fused_kernel", {}).get("bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "match_kernel<materialised sim> (N x 8192 descriptor-distance kernel)", "bound": "hbm",
-                "achieved": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(mat_bytes / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": mat_bytes, "avg_ms": round(mat_ms, 4),
-                "mfma_tflops": round(mfma_flops / (mat_ms * 1e-3) / 1e12, 2)}
+    line = {
+        "metric": "rgbd_crops_per_sec_geomatch_fwd", "value": round(value, 2), "unit": "crops/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.exact_f32 else "bf16x3/f32acc", "data": "synthetic",
+        "config": {"workload": "LineMOD obj_01 batch=%d/GPU, N=%d scene pts x M=%d model kps, crop 256x256, geoMatch "
+                               "(CNN+RandLA+SplineCNN) fwd-only + kNN pyramid + matching" % (B, N, M),
+                   "batch_per_gpu": B, "global_batch": B * world, "n_points": N, "n_model": M,
+                   "match_precision": args.precision,
+                   "product_arithmetic": "exact f32" if args.exact_f32 else
+                   "split-bf16 MFMA x3 (fp32 accumulate) for matching, trunk convolutions and 1x1 mixes; f32 elsewhere",
+                   "launch": launch, "side_streams": bool(settings.USE_SIDE_STREAMS),
+                   "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
+        "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
+                     "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
+        "graph_check": check,
+        "eager": {"ms_per_step": round(dt_eager / args.steps * 1e3, 3), "crops_per_s": round(B * args.steps / dt_eager, 1),
+                  "host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3)},
+        "roofline": None, "roofline_fused": None, "rooflines": None, "cpu_baseline": None, "extras": None,
+        "build": _lib.build_record(),
+    }
+    printed = []
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cpu = cpu_baseline(batch, sd_cpu, args.cpu_crops, B)
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(1)
+            print(json.dumps(line), flush=True)
 
-    extras, rooflines = None, None
-    if rank == 0 and world == 1 and not args.no_extras:
-        extras = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "eager_crops_per_s": round(B * args.steps / dt_eager, 1),
-                  "eager_host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3),
-                  "note": "eager = one host call per kernel (~240 per step): a rank then needs a host core of its own; the headline's "
-                          "graph replay needs one call per step"}
-        extras.update(extra_legs(torch, dev, args, model, N, M))
-        rooflines = [dict(roofline, name="match materialised"), dict(roofline_fused, name="match fused")] + kernel_rooflines(torch, dev, B, N)
+    # from here on nothing may cost the headline: every later section is guarded, and SIGTERM prints what is there
+    import signal
 
+    def on_term(signum, frame):
+        line["terminated"] = "signal %d after %.0f s" % (signum, time.perf_counter() - t_start)
+        emit()
+        os._exit(4 if (check is None or check.get("ok")) else 3)
     if rank == 0:
-        arith = "exact f32" if args.exact_f32 else ("split-bf16 MFMA x3 (fp32 accumulate) for matching, 32x32-res 3x3 convs and large "
-                                                    "1x1 mixes; f32 elsewhere")
-        line = {
-            "metric": "rgbd_crops_per_sec_geomatch_fwd", "value": round(value, 2), "unit": "crops/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.exact_f32 else "bf16x3/f32acc", "data": "synthetic",
-            "config": {"workload": "LineMOD obj_01 batch=%d/GPU, N=%d scene pts x M=%d model kps, crop 256x256, geoMatch "
-                                   "(CNN+RandLA+SplineCNN) fwd-only + kNN pyramid + matching" % (B, N, M),
-                       "batch_per_gpu": B, "global_batch": B * world, "n_points": N, "n_model": M,
-                       "match_precision": args.precision, "product_arithmetic": arith,
-                       "launch": "eager (one host call per kernel)" if args.eager else "hipGraph replay of the whole step (one host call per step)",
-                       "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
-            "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
-                         "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
-            "roofline": roofline, "roofline_fused": roofline_fused, "rooflines": rooflines, "cpu_baseline": cpu, "extras": extras,
-        }
-        print(json.dumps(line))
+        signal.signal(signal.SIGTERM, on_term)
+
+    # ---- roofline of the N x M descriptor kernel (SURVEY.md 8d) -------------------------------------
+    try:
+        flops = 2.0 * B * N * M * 128
+        mat_bytes = 4.0 * 128 * (B * N + M) + 4.0 * B * N * M
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16x3" else MFMA_F32_PEAK_TFLOPS
+        mfma_flops = flops * (3.0 if args.precision == "bf16x3" else 1.0)    # executed MFMA work: hi*hi + hi*lo + lo*hi
+        mat_ms = fused_ms = float("nan")
+        with torch.no_grad():
+            d = dict(inputs)
+            d.update(pyramid.build_pyramid(cld, dpt_xyz))
+            ep = model(d)
+            srows = ops.match_pack(ep["rgbd"], prec)
+            mrows = ops.match_pack(ep["mesh"][0], prec)
+            sim = torch.empty((B, N, M), dtype=torch.float32, device=dev) if rank == 0 else None
+            for _ in range(3 if rank == 0 else 0):
+                ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
+            torch.cuda.synchronize()
+            # ONE event pair around K back-to-back launches (each = the N x M kernel + the 4-us split merge) on the stream they are
+            # launched on: an event pair per launch adds ~20 us of marker handling to every sample (8 % of this kernel)
+            n_launch = max(args.steps, 10) if rank == 0 else 0
+            if n_launch:
+                a, b = ev(), ev()
+                a.record()
+                for _ in range(n_launch):
+                    ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
+                b.record()
+                torch.cuda.synchronize()
+                mat_ms = a.elapsed_time(b) / n_launch
+                a, b = ev(), ev()
+                a.record()
+                for _ in range(n_launch):
+                    ops.match_packed(srows, mrows, B, N, M, prec)
+                b.record()
+                torch.cuda.synchronize()
+                fused_ms = a.elapsed_time(b) / n_launch
+            del sim
+        roofline_fused = {"kernel": "match_kernel<fused arg-max> (+ split merge), back-to-back launches as the one the step issues", "bound": "mfma",
+                          "achieved": round(mfma_flops / (fused_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                          "frac": round(mfma_flops / (fused_ms * 1e-3) / 1e12 / peak_tf, 4),
+                          "algorithmic_tflops": round(flops / (fused_ms * 1e-3) / 1e12, 2),
+                          "avg_ms": round(fused_ms, 4), "traffic": None}
+        # PMC traffic comes from separate rocprofv3 --pmc passes (profiles/match_traffic.json), valid for the headline shape only
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "match_traffic.json")
+        if os.path.exists(tfile) and (B, N, M, args.precision) == (16, 2048, 8192, "bf16x3"):
+            try:
+                tj = json.load(open(tfile))
+                traffic = tj.get("materialised_bytes_per_launch")
+                roofline_fused["traffic"] = tj.get("fused_kernel", {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line["roofline"] = {"kernel": "match_kernel<materialised sim> (N x 8192 descriptor-distance kernel)", "bound": "hbm",
+                            "achieved": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(mat_bytes / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                            "algorithmic_bytes_per_launch": mat_bytes, "avg_ms": round(mat_ms, 4),
+                            "mfma_tflops": round(mfma_flops / (mat_ms * 1e-3) / 1e12, 2)}
+        line["roofline_fused"] = roofline_fused
+    except Exception as e:                                     # noqa: BLE001
+        line["roofline"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            line["cpu_baseline"] = cpu_baseline(batch, sd_cpu, args.cpu_crops, B)
+        except Exception as e:                                 # noqa: BLE001
+            line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        ex = {}
+        _leg(ex, "light", lambda: ex.update(light_extras(torch, dev, args, model, N, M)))
+        line["extras"] = ex
+        try:
+            line["rooflines"] = ([dict(line["roofline"], name="match materialised"), dict(line["roofline_fused"], name="match fused")]
+                                 + kernel_rooflines(torch, dev, B, N))
+        except Exception as e:                                 # noqa: BLE001
+            line["rooflines"] = [{"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}]
+
+    emit()                                                     # THE one JSON line on stdout: before the long legs below
+
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_heavy_extras:
+        heavy = heavy_extras(torch, dev, args, model, N, M)
+        sys.stderr.write("bench extras (after the JSON line): " + json.dumps(heavy) + "\n")
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(out_dir, exist_ok=True)
+            with open(os.path.join(out_dir, "bench_extras.json"), "w") as f:
+                json.dump({"headline": line, "extras_after_line": heavy}, f, indent=1)
+        except OSError:
+            pass
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check.get("ok"):
+        sys.exit(3)                                            # the line is out; the exit code says the replay was outside tolerance
 
 
 if __name__ == "__main__":

@@ -122,11 +122,59 @@ SIGNATURES = {
 _lib = None
 
 
+def _objects_state():
+    st = {}
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".o"):
+            st[f] = os.stat(os.path.join(CSRC, f)).st_mtime_ns
+    return st
+
+
 def build(verbose=False):
-    """hipcc --offload-arch=gfx950 build of libgdm_hip.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 build of libgdm_hip.so (cross-compiles without a GPU).  Writes csrc/build_record.json: which
+    translation units this call recompiled (`make` decides by time stamps) and the library's size / SHA-256 -- the evidence of what
+    was built, read back by `build_record()` (bench.py prints it with its line)."""
+    import hashlib
+    import json
+    import time
+    before = _objects_state()
     out = None if verbose else subprocess.DEVNULL
+    t0 = time.time()
     subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=out)
+    after = _objects_state()
+    rebuilt = sorted(f for f, m in after.items() if before.get(f) != m)
+    with open(LIB_PATH, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()[:16]
+    rec = {"mode": "hipcc --offload-arch=gfx950 via csrc/Makefile (in-tree, ahead of time)", "recompiled": rebuilt,
+           "up_to_date": sorted(set(after) - set(rebuilt)), "lib": os.path.basename(LIB_PATH), "lib_bytes": os.path.getsize(LIB_PATH),
+           "lib_sha256_16": digest, "seconds": round(time.time() - t0, 1), "when": time.strftime("%Y-%m-%dT%H:%M:%S")}
+    try:
+        with open(os.path.join(CSRC, "build_record.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+    print("[gdm build] recompiled %d of %d translation units%s; %s %d bytes sha256 %s" %
+          (len(rebuilt), len(after), (": " + " ".join(rebuilt)) if rebuilt else "", rec["lib"], rec["lib_bytes"], digest))
     return LIB_PATH
+
+
+def build_record():
+    """What `build()` last recorded, plus the SHA-256 of the library that is actually loaded (they must agree)."""
+    import hashlib
+    import json
+    rec = {}
+    try:
+        with open(os.path.join(CSRC, "build_record.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        rec = {"mode": "prebuilt library (no build record travelled)"}
+    try:
+        with open(LIB_PATH, "rb") as f:
+            rec["loaded_lib_sha256_16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        rec["loaded_lib_sha256_16"] = None
+    rec.pop("up_to_date", None)
+    return rec
 
 
 def lib():

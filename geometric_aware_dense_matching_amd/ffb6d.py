@@ -178,12 +178,11 @@ class FFB6DEmb(nn.Module):
         else:
             pre = self.cnn_pre_stages
             rgb_emb = pre[3](bn_act(pre[1], pre[0](inputs["rgb"]), pre[2]))
-        # Inference: the point branch of every encoder stage (RandLA block + pooling: a dozen small launches) is forked onto a side
-        # stream beside the image branch's convolutions; they meet at the fusion.  An overlapped neighbour-pyramid build
-        # (pyramid.build_pyramid(..., overlap=True)) is waited for where the first index is consumed, not at the top.
+        # Inference, settings.USE_SIDE_STREAMS (off by default): the point branch of every encoder stage (RandLA block + pooling) is
+        # forked onto side stream 0 beside the image branch's convolutions; they meet at the fusion.  An overlapped neighbour-pyramid
+        # build (pyramid.build_pyramid(..., overlap=True)) is waited for by EACH consuming stream before its first index use.
         from . import pyramid as _pyr
         overlap = settings.USE_SIDE_STREAMS and "point" in settings.SIDE_PARTS and fused_eval(inputs["rgb"], self)
-        ready = inputs.get(_pyr.READY)
         if not overlap:
             _pyr.wait_ready(inputs)
         p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
@@ -191,10 +190,16 @@ class FFB6DEmb(nn.Module):
         ds_emb = []
         for i_ds in range(4):
             if overlap:
-                with ops.fork(inputs["rgb"].device, 0, after=ready if i_ds == 0 else None) as f:
-                    f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
-                    p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
+                xyz_i, nei_i, sub_i = inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds], inputs["cld_sub_idx%d" % i_ds]
+                with ops.fork(inputs["rgb"].device, 0) as f:
+                    if i_ds == 0:
+                        _pyr.wait_ready(inputs)                               # the side stream's own wait
+                    f.use(p_emb, xyz_i, nei_i, sub_i)
+                    f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, xyz_i, nei_i)
+                    p_emb0 = self.random_sample(f_encoder_i, sub_i)
                 rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
+                if i_ds == 0:
+                    _pyr.wait_ready(inputs)                                   # the main stream's own wait, before its first index use
                 f.join(f_encoder_i, p_emb0)
             else:
                 rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)

@@ -182,7 +182,7 @@ class GeoMatch(nn.Module):
         rgb = inputs["rgb"]
         if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
             # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
-            with ops.fork(rgb.device, 1) as f:
+            with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
                 mesh_features = self.mesh_features()
             rgbd_emb = self.pcd_emb(inputs)
             f.join(mesh_features)

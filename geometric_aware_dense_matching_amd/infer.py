@@ -7,7 +7,7 @@ results come back in the original instance order with the reference's concatenat
 (`seg [bs,2,N]`, `rgbd [bs,128,N]`, `mesh [bs,128,M]`)."""
 import torch
 
-from . import matching, pose, pyramid
+from . import matching, ops, pose, pyramid
 
 
 def run_multi_object(model_dict, inputs, cls_ids, with_pose=True, precision="bf16x3"):
@@ -52,15 +52,16 @@ class GraphedPipeline:
         self.model = model.eval()
         self.precision, self.with_pose = precision, with_pose
         self.static_in = {k: v.clone() for k, v in example_inputs.items() if torch.is_tensor(v)}
+        self.pool = ops.BufferPool()                                 # this graph's scratch buffers (and their captured zero fills)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s), torch.no_grad():
-            for _ in range(warmup):                                  # MIOpen picks its kernels, caches fill
+        with torch.cuda.stream(s), torch.no_grad(), ops.buffer_pool(self.pool):
+            for _ in range(warmup):                                  # per-module caches fill
                 self._step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph), ops.buffer_pool(self.pool):
             self.static_out = self._step()
 
     def _step(self):

@@ -44,19 +44,25 @@ def side_stream(device, which=0):
 
 
 class fork:
-    """with ops.fork(device, which) as side: ...   -- the body is enqueued on a side stream that starts after everything already on
-    the current stream; `join()` afterwards makes the current stream wait for it.  Works eagerly and inside hipGraph capture."""
+    """with ops.fork(device, which) as f: ...   -- the body is enqueued on side stream `which`, which first waits for everything
+    already on the current stream (and for the `after` events, if given); `f.join(*tensors)` afterwards makes the current stream
+    wait for the side stream and hands the tensors made there over to it.  Works eagerly and inside hipGraph capture.
 
-    def __init__(self, device, which=0, after=None):
+    Lifetime rule (explicit, no argument by allocator behaviour): every tensor that crosses a stream is `record_stream`ed on the
+    stream that did not allocate it -- `f.use(t)` for a tensor of the current stream that the body reads, `f.join(t, ...)` for
+    the tensors the body made -- so the caching allocator never hands its block out again before both streams are done with it."""
+
+    def __init__(self, device, which=0, after=()):
         self.side = side_stream(device, which)
         self.cur = torch.cuda.current_stream(device)
-        self.after = after
+        self.after = tuple(after) if isinstance(after, (tuple, list)) else (after,)
         self._ctx = None
 
     def __enter__(self):
         self.side.wait_stream(self.cur)
-        if self.after is not None and self.after[1] is not self.side:      # (event, stream it was recorded on): same stream = ordered
-            self.side.wait_event(self.after[0])
+        for ev in self.after:
+            if ev is not None:
+                self.side.wait_event(ev)           # waiting for an event of the same stream is free
         self._ctx = torch.cuda.stream(self.side)
         self._ctx.__enter__()
         return self
@@ -65,11 +71,18 @@ class fork:
         self._ctx.__exit__(*exc)
         return False
 
+    def use(self, *tensors):
+        """Tensors allocated on the current stream that the forked body reads."""
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.side)
+
     def join(self, *tensors):
-        """Tensors made on the side stream may be used on the current stream from here on.  No record_stream is needed: a side
-        stream only ever runs inside fork(), which begins by waiting for the current stream, so by the time a freed block can be
-        handed out again on the side stream every consumer already enqueued on the current stream is ordered before it."""
+        """The current stream waits for the side stream; `tensors` (made on the side stream) may be used on it from here on."""
         self.cur.wait_stream(self.side)
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.cur)
 
 
 def _dev(t, dtype, name):
@@ -107,7 +120,7 @@ def knn_batch(support, query, K, return_d2=False):
     return (idx, d2) if return_d2 else idx
 
 
-def knn_jobs(jobs, B):
+def knn_jobs(jobs, B, keep_workspace=None):
     """jobs: list of (support f32 view [B,S,3], query f32 view [B,Q,3], K[, grid_w]).  Views may be prefix
     slices along dim 1 of contiguous [B,N,3] arrays (batch stride kept).  grid_w > 0 declares the support an organised map of
     S / grid_w rows x grid_w columns (row-major pixels of a depth crop): K > 1 searches then scan only the window of pixel
@@ -137,7 +150,9 @@ def knn_jobs(jobs, B):
         arr[i].grid_w = grid_w if (grid_w > 0 and S % grid_w == 0) else 0
         outs.append(out)
         keep.append((sup, qry))
-    _knn_launch(arr, n, B, jobs[0][0].device)
+    ws = _knn_launch(arr, n, B, jobs[0][0].device)
+    if keep_workspace is not None:
+        keep_workspace.append(ws)        # the caller keeps it alive as long as the results (explicit lifetime across streams)
     return outs
 
 
@@ -148,6 +163,7 @@ def _knn_launch(arr, n, B, device):
     nbytes = int(L.gdm_knn_jobs_workspace_bytes(arr, n, B))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
     check(L.gdm_knn_jobs_ws_hip(arr, n, B, ws.data_ptr(), nbytes, _stream()), "gdm_knn_jobs_ws_hip")
+    return ws
 
 
 def ballquery(radius, nsample, xyz, new_xyz):
@@ -970,7 +986,52 @@ def psp_combine_train(g, ys, bias):
     return _PspCombine.apply(g, bias, ys[0], ys[1], ys[2], ys[3])
 
 
-_conv_act_cache = {}
+class BufferPool:
+    """Owner-held scratch buffers of the split-bf16 kernels (zero-bordered packed activation maps, matching workspaces).  Whoever
+    captures a step in a hipGraph owns one (infer.GraphedPipeline, train_graph.GraphedTrainStep, bench.py's step) and enters it
+    with `ops.buffer_pool(pool)` around warm-up, capture and any later eager call of the same step: the buffers -- and the zero
+    fill of their borders, captured once per buffer -- then belong to that graph's private memory pool and to nothing else.
+    Eager code outside any scope uses the process-wide default pool."""
+
+    def __init__(self):
+        self.packed = {}
+        self.workspace = {}
+
+
+_default_pool = BufferPool()
+_pool = _default_pool
+_warned_capture = []
+
+
+class buffer_pool:
+    def __init__(self, pool):
+        self.pool, self.prev = pool, None
+
+    def __enter__(self):
+        global _pool
+        self.prev, _pool = _pool, self.pool
+        return self.pool
+
+    def __exit__(self, *exc):
+        global _pool
+        _pool = self.prev
+        return False
+
+
+def _capturing_unscoped():
+    """A hipGraph capture that runs outside any buffer_pool scope: its scratch buffers must not enter (or come from) the
+    process-wide pool -- they would live in this graph's private memory pool, and a later capture of the same shape would
+    silently write into them -- so they are allocated per call (each zero fill is then replayed with the graph: slower, correct)."""
+    if _pool is _default_pool and torch.cuda.is_current_stream_capturing():
+        if not _warned_capture:
+            _warned_capture.append(1)
+            import warnings
+            warnings.warn("geometric_aware_dense_matching_amd.ops: hipGraph capture outside ops.buffer_pool(...): scratch buffers "
+                          "are allocated per call inside the graph; give the capture a BufferPool of its own")
+        return True
+    return False
+
+
 
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1)):
@@ -1005,14 +1066,17 @@ class PackedAct:
 
 
 def _packed_buffer(B, C, H, W, device, avoid=None):
-    """Zero-bordered operand buffer for [B,C,H,W] from a small per-shape pool (two per shape and stream: a layer reads one and
+    """Zero-bordered operand buffer for [B,C,H,W] from the current BufferPool (two per shape and stream: a layer reads one and
     writes the other).  Only interior pixels are ever written, so the border stays zero."""
+    nbytes = _lib.lib().gdm_conv3x3_act_bytes(B, C, H, W)
+    if _capturing_unscoped():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
     key = (B, C, H, W, device.index, torch.cuda.current_stream().cuda_stream)
-    pool = _conv_act_cache.setdefault(key, [])
+    pool = _pool.packed.setdefault(key, [])
     for buf in pool:
         if avoid is None or buf.data_ptr() != avoid.data_ptr():
             return buf
-    buf = torch.zeros(_lib.lib().gdm_conv3x3_act_bytes(B, C, H, W), dtype=torch.uint8, device=device)
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     pool.append(buf)
     return buf
 
@@ -1206,15 +1270,14 @@ def upsample_bilinear(x, size):
 # --------------------------------------------------------------------------------------
 # matching
 # --------------------------------------------------------------------------------------
-_ws_cache = {}
-
-
 def _workspace(nbytes, device):
+    if _capturing_unscoped():
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _ws_cache.get(key)
+    ws = _pool.workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+        _pool.workspace[key] = ws
     return ws
 
 

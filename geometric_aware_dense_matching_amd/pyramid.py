@@ -27,21 +27,26 @@ def cloud_from_inputs(cld_rgb_nrm):
 
 
 READY = "_pyramid_ready"          # key of the event recorded behind an overlapped pyramid build
+KEEP = "_pyramid_keep"            # key of the buffers the build keeps alive with its results (kNN workspace, strided grids)
+PYR_STREAM = 2                    # side-stream number of an overlapped build (its own: the point branch forks onto 0, the mesh branch onto 1)
 
 
 def build_pyramid(cld, dpt_xyz, overlap=False):
-    """overlap=True (inference): the searches are enqueued on a side stream, so that the image trunk's first stages -- which
-    need no indices -- run beside them; the returned dict then carries the event every consumer must wait for under READY
-    (FFB6DEmb.forward does; `wait_ready(pyr)` for other consumers)."""
+    """overlap=True (inference, settings.USE_SIDE_STREAMS with "pyr" in SIDE_PARTS): the searches are enqueued on a side stream of
+    their own, so that the image trunk's first stages -- which need no indices -- run beside them; the returned dict then carries
+    the event EVERY consuming stream must wait for under READY (FFB6DEmb.forward does, on the main stream and on the point
+    branch's fork; `wait_ready(pyr)` for other consumers).  Its tensors are allocated on that side stream; `wait_ready` also
+    records them on the consuming stream, so their blocks are not reused while that stream still reads them."""
     if not (cld.is_cuda and dpt_xyz.is_cuda):
         raise RuntimeError("build_pyramid runs on the GPU (HIP kNN); there is no CPU fallback")
     from . import settings
     if overlap and settings.USE_SIDE_STREAMS and "pyr" in settings.SIDE_PARTS:
-        with ops.fork(cld.device, 0) as f:
+        with ops.fork(cld.device, PYR_STREAM) as f:
+            f.use(cld, dpt_xyz)
             pyr = build_pyramid(cld, dpt_xyz)
             ev = torch.cuda.Event()
             ev.record(f.side)
-        pyr[READY] = (ev, f.side)
+        pyr[READY] = ev
         return pyr
     B, N, _ = cld.shape
     S = dpt_xyz.shape[1]
@@ -66,9 +71,11 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
         pts, px = levels[3 - i], grids[RGB_UP_SR[i]]
         jobs += [(px, pts, K_NEI, S // RGB_UP_SR[i]), (pts, px, 1)]
         names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
-    outs = ops.knn_jobs(jobs, B)
+    keep = [grids[sc] for sc in (2, 4, 8)]
+    outs = ops.knn_jobs(jobs, B, keep_workspace=keep)
 
     pyr = dict(zip(names, outs))
+    pyr[KEEP] = keep
     for i in range(4):
         # prefix views are batch-strided; every consumer (two LFA stage launches per level, the pooling gather) wants them dense,
         # so they are made contiguous once here instead of once per use
@@ -78,7 +85,15 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
 
 
 def wait_ready(inputs, stream=None):
-    """Make `stream` (default: the current one) wait for an overlapped pyramid build, if the inputs carry one."""
+    """Make `stream` (default: the current one) wait for an overlapped pyramid build, if the inputs carry one, and record the
+    pyramid's tensors on it.  Idempotent and cheap: every consuming stream calls it before its first index use."""
     ev = inputs.get(READY)
-    if ev is not None:
-        (stream or torch.cuda.current_stream()).wait_event(ev[0])
+    if ev is None:
+        return
+    st = stream or torch.cuda.current_stream()
+    st.wait_event(ev)
+    for k, v in inputs.items():
+        if torch.is_tensor(v) and v.is_cuda and (k.startswith("cld_") and k[4:7] in ("xyz", "nei", "sub", "int") or "_nei_idx" in k):
+            v.record_stream(st)
+    for v in inputs.get(KEEP, ()):
+        v.record_stream(st)

@@ -1,5 +1,6 @@
 """Runtime A/B switches of the package, in ONE place.  Every switch selects between a hand-written HIP path and the plain
-form it replaces (the form the parity tests tie it to); all default to the HIP path.  They are read at CALL time
+form it replaces (the form the parity tests tie it to); all default to the HIP path (USE_SIDE_STREAMS and
+STATIC_MATCH_ROWS are the two that default to off).  They are read at CALL time
 (`settings.USE_X`), so a test or a benchmark may flip one between two calls; the `GDM_*` environment variables only set
 the initial values.
 
@@ -15,8 +16,9 @@ the initial values.
     USE_FUSED_BN_TRAIN         GDM_FUSED_BN_TRAIN         training BatchNorm + activation on the torch modules
     USE_FUSED_SYNCBN           GDM_FUSED_SYNCBN           nn.SyncBatchNorm on torch's implementation
     USE_FUSED_MATCH_LOSS       GDM_FUSED_MATCH_LOSS       training similarity materialised by hipBLASLt, rows kernel for the circle loss
-    USE_SIDE_STREAMS           GDM_SIDE_STREAMS           everything on the caller's stream (inference otherwise forks the mesh branch, the
-                                                          neighbour pyramid and the point branch of each encoder stage onto side streams)
+    USE_SIDE_STREAMS           GDM_SIDE_STREAMS=1         (default OFF: everything on the caller's stream) inference forks the mesh branch, the
+                                                          neighbour pyramid and the point branch of each encoder stage onto side streams
+                                                          (worth ~3 % of the step; see DESIGN.md "Side streams")
     UPCONV_MIN_CIN             GDM_UPCONV_MIN_CIN         (int) smallest Cin for the low-resolution form of conv3x3(upsample(x))
     USE_SPARSE_FINAL           GDM_SPARSE_FINAL           the last image stage (up_3 + final) on the full 2x map, then the gather with `choose`
                                                           (default: evaluated at the chosen pixels only -- inference, 1/32 of the pixels)
@@ -43,7 +45,7 @@ USE_GROUPED_SPLINE = _flag("GDM_GROUPED_SPLINE")
 USE_FUSED_BN_TRAIN = _flag("GDM_FUSED_BN_TRAIN")
 USE_FUSED_SYNCBN = _flag("GDM_FUSED_SYNCBN")
 USE_FUSED_MATCH_LOSS = _flag("GDM_FUSED_MATCH_LOSS")
-USE_SIDE_STREAMS = _flag("GDM_SIDE_STREAMS")
+USE_SIDE_STREAMS = _flag("GDM_SIDE_STREAMS", "0")
 USE_SPARSE_FINAL = _flag("GDM_SPARSE_FINAL")
 USE_FUSED_HEADS = _flag("GDM_FUSED_HEADS")
 USE_MFMA_STRIDED = _flag("GDM_MFMA_STRIDED")

@@ -11,7 +11,7 @@ BatchNorm momentum is a kernel argument, so a momentum change (every `decay_step
 """
 import torch
 
-from . import train_lm
+from . import ops, train_lm
 
 _INPUT_KEYS = None          # every tensor entry of the collated batch is an input
 
@@ -56,11 +56,13 @@ class GraphedTrainStep:
         self.momenta = None
         self.captures = 0
         self.stream = torch.cuda.Stream(device)
+        self.pool = ops.BufferPool()               # scratch buffers of the captured iteration (ops.buffer_pool)
 
     # ---- one eager iteration on static buffers (what the capture records) -------------------------------------------------------
     def _iteration(self):
-        out, _ = train_lm.model_fn_dec(self.model, dict(self.static_in), self.device)
-        out["loss"].backward()
+        with ops.buffer_pool(self.pool):
+            out, _ = train_lm.model_fn_dec(self.model, dict(self.static_in), self.device)
+            out["loss"].backward()
         self.optimizer.step()
         return {k: torch.as_tensor(out[k], device=self.device).detach().float() for k in ("loss", "seg_loss", "match_loss")}
 

@@ -185,6 +185,7 @@ class Trainer:
                     sums = vals if sums is None else sums + vals
                     dev_hist.append(vals)
                     if (it + 1) % self.log_every == 0:
+                        self._flush_history(dev_hist)            # the one host read of this log window; frees the per-iteration scalars
                         if self.local_rank == 0:
                             print("avg_loss:{:.4f} seg: {:.4f} match: {:.4f}  time cost:{:.1f} s".format(
                                 *(sums / self.log_every).tolist(), time.time() - t0))
@@ -205,8 +206,16 @@ class Trainer:
                     save_checkpoint(self.model, self.optimizer, epoch, self.checkpoint_dir, self.obj_name)
             return it_total
         finally:
-            if dev_hist:
-                self.history += [tuple(v) for v in torch.stack(dev_hist).cpu().tolist()]
+            self._flush_history(dev_hist)
+
+    HISTORY_CAP = 100000          # `history` keeps the most recent iterations' (loss, seg, match) triples
+
+    def _flush_history(self, dev_hist):
+        if dev_hist:
+            self.history += [tuple(v) for v in torch.stack(dev_hist).cpu().tolist()]
+            dev_hist.clear()
+            if len(self.history) > self.HISTORY_CAP:
+                del self.history[:len(self.history) - self.HISTORY_CAP]
 
 
 def make_dataset(args, split, cls_ids=None):

@@ -311,3 +311,99 @@ def test_dgcnn_variant_all_entries_with_reference_graphs():
     for name in ("rgbd", "seg", "mesh"):
         t = ep2[name].float().cpu()
         assert abs(t.double().norm().item() - float(g[name + "_norm"])) < 2e-3 * float(g[name + "_norm"])
+
+
+def _bench_step(model, inputs, cld, dpt_xyz, B, overlap=True):
+    """Exactly bench.py's step: pyramid (overlap=True) + forward + seg mask + pack + N x M arg-max; returns every intermediate."""
+    from geometric_aware_dense_matching_amd import ops, pyramid
+    pyr = pyramid.build_pyramid(cld, dpt_xyz, overlap=overlap)
+    d = dict(inputs)
+    d.update(pyr)
+    ep = model(d)
+    mask, count = ops.seg_mask(ep["seg"])
+    srows = ops.match_pack(ep["rgbd"], ops.MATCH_BF16X3)
+    mrows = ops.match_pack(ep["mesh"][0], ops.MATCH_BF16X3)
+    bi, bs = ops.match_packed(srows, mrows, B, N2, M2, ops.MATCH_BF16X3)
+    out = {k: v for k, v in pyr.items() if torch.is_tensor(v)}
+    out.update(rgbd=ep["rgbd"], seg=ep["seg"], mesh=ep["mesh"], mask=mask, best_idx=bi, best_sim=bs)
+    return out
+
+
+def test_timed_configuration_bit_exact_across_launch_forms(headline_model):
+    """The configuration bench.py TIMES (B=16, N=2048, M=8192, build_pyramid(overlap=True), hipGraph capture), strictly:
+      (1) all 30 pyramid arrays of all 16 crops bit-equal to oracle/pyramid.py (linemod_pbr.py:515-569);
+      (2) hipGraph replay == eager step, torch.equal on every output (pyramid, rgbd, seg, mesh, mask, arg-max indices, maxima);
+      (3) the same with the side-stream forks ON (settings.USE_SIDE_STREAMS, every fork) vs OFF, eager and replayed;
+      (4) overlap=True == overlap=False;
+      (5) crops 0, 7, 15: arg-max / maxima vs the oracle's matching lines on the product's descriptors (1e-4, north_star).
+    The step is made of own kernels without float atomics (the stem included), so equality is exact, not approximate."""
+    from geometric_aware_dense_matching_amd import ops, pyramid, settings
+    from oracle import ops_ref
+    from oracle import pyramid as opyr
+    model, _ = headline_model
+    B = 16
+    batch = synthetic.make_batch(seed=100, batch=B, n_points=N2)                          # bench.py's seed for rank 0
+    inputs = {k: torch.from_numpy(batch[k]).cuda() for k in ("rgb", "cld_rgb_nrm", "choose")}
+    dpt_xyz = torch.from_numpy(batch["dpt_xyz"]).cuda()
+    cld = pyramid.cloud_from_inputs(inputs["cld_rgb_nrm"])
+    saved = (settings.USE_SIDE_STREAMS, list(settings.SIDE_PARTS))
+
+    def snap(o):
+        return {k: v.clone() for k, v in o.items()}
+
+    def same(a, b, what):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "%s: %s differs (%d entries)" % (what, k, int((a[k] != b[k]).sum()))
+
+    def graphed(tag):
+        pool = ops.BufferPool()
+        with ops.buffer_pool(pool):
+            for _ in range(2):
+                _bench_step(model, inputs, cld, dpt_xyz, B)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = _bench_step(model, inputs, cld, dpt_xyz, B)
+        shots = []
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            shots.append(snap(out))
+        for _ in range(5):                                                                # back to back, as the timed loop replays
+            g.replay()
+        torch.cuda.synchronize()
+        shots.append(snap(out))
+        return shots
+
+    try:
+        with torch.no_grad():
+            settings.USE_SIDE_STREAMS = False
+            ref = snap(_bench_step(model, inputs, cld, dpt_xyz, B))
+            torch.cuda.synchronize()
+            # (1) neighbour pyramid vs the oracle, every crop, every array
+            for i in range(B):
+                want = opyr.build_pyramid(batch["cld_rgb_nrm"][i, :3].T.copy(), batch["dpt_xyz"][i])
+                assert len(want) == 30
+                for k, v in want.items():
+                    assert np.array_equal(ref[k][i].cpu().numpy(), v), "crop %d %s" % (i, k)
+            # (4) overlap flag, (2) replays
+            same(ref, snap(_bench_step(model, inputs, cld, dpt_xyz, B, overlap=False)), "overlap=False")
+            same(ref, snap(_bench_step(model, inputs, cld, dpt_xyz, B)), "second eager step")
+            for i, s in enumerate(graphed("off")):
+                same(ref, s, "graph replay %d (forks off)" % i)
+            # (3) forks on: eager and replayed
+            settings.USE_SIDE_STREAMS = True
+            settings.SIDE_PARTS = ["mesh", "point", "pyr"]
+            same(ref, snap(_bench_step(model, inputs, cld, dpt_xyz, B)), "eager step with side-stream forks")
+            for i, s in enumerate(graphed("on")):
+                same(ref, s, "graph replay %d (forks on)" % i)
+        # (5) matching of the product's descriptors vs the oracle
+        mesh_cpu = ref["mesh"][0].cpu()
+        for b in (0, 7, 15):
+            wv, wi, ws = ops_ref.match_argmax(ref["rgbd"][b].cpu(), mesh_cpu)
+            assert (ref["best_sim"][b].cpu() - wv).abs().max() < 1e-4
+            at = ws.gather(1, ref["best_idx"][b].cpu().long().unsqueeze(1)).squeeze(1)
+            assert ((wv - at) < 1e-4).all()
+            assert (ref["best_idx"][b].cpu().long() == wi).float().mean() > 0.999
+    finally:
+        settings.USE_SIDE_STREAMS, settings.SIDE_PARTS = saved

@@ -443,7 +443,7 @@ def test_gpu_front_end_vs_synthetic_generator(golden_model):
 
 
 def test_graphed_pipeline_equals_eager(golden_model):
-    """One hipGraph replay of pyramid + forward + matching + pose == the eager step on new inputs."""
+    """One hipGraph replay of pyramid + forward + matching + pose == the eager step on new inputs (bit-exact: the eval step has no float atomics)."""
     from geometric_aware_dense_matching_amd import infer, matching, pose, pyramid
     model, _ = golden_model
     b0 = _dev_inputs(synthetic.make_batch(seed=61, batch=2, n_points=1024))
@@ -458,8 +458,11 @@ def test_graphed_pipeline_equals_eager(golden_model):
         ep = model(d)
         res = matching.match_frames(ep)
         RT, valid = pose.solve_poses(res, d["cld_rgb_nrm"], model.model_emb.xyz)
-    assert torch.allclose(got["rgbd"], ep["rgbd"], rtol=1e-4, atol=1e-4)
-    assert (got["best_idx"] == res["best_idx"]).float().mean().item() > 0.995
+    # same shapes, same kernels, no float atomics in the eval step: a replay on new inputs equals the eager step bit for bit
+    for k in ("rgbd", "seg", "mesh"):
+        assert torch.equal(got[k], ep[k]), k
+    for k in ("mask", "best_idx", "best_sim"):
+        assert torch.equal(got[k], res[k]), k
     assert torch.equal(got["valid"], valid)
     if bool(valid.all()):
         assert torch.allclose(got["RT"], RT, atol=1e-3)
