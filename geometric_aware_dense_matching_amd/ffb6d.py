@@ -111,12 +111,13 @@ class FFB6DEmb(nn.Module):
         return cache[1], cache[2]
 
     @staticmethod
-    def _fuse_weight_t(layer, wa):
+    def _fuse_weight_t(layer, wa, tag="a"):
         """wa transposed ([ci][co], contiguous), cached beside the split weights."""
-        cache = layer.__dict__.get("_gdm_wa_t")
+        slot = "_gdm_w%s_t" % tag
+        cache = layer.__dict__.get(slot)
         if cache is None or cache[0] is not wa:
             cache = (wa, wa.t().contiguous())
-            layer.__dict__["_gdm_wa_t"] = cache
+            layer.__dict__[slot] = cache
         return cache[1]
 
     def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False):
@@ -134,7 +135,10 @@ class FFB6DEmb(nn.Module):
                     # gathered point) by the same library GEMM with its operands swapped
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
                     pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
-                    t_pm = torch.matmul(pp.transpose(1, 2), wb.t())                       # [B, n', 64]
+                    if settings.USE_POINTWISE:
+                        t_pm = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"), point_major=True)   # [B, n', 64]
+                    else:
+                        t_pm = torch.matmul(pp.transpose(1, 2), wb.t())
                     cache = fuse_layer.__dict__.get("_gdm_wa_pk")
                     if cache is None or cache[0] is not wa:
                         cache = (wa, ops.pack_rows64(wa))
@@ -142,7 +146,11 @@ class FFB6DEmb(nn.Module):
                     y = ops.conv64_gather_add_act_mfma(rgb_emb0.reshape(bs, c, hr * wr), cache[1], t_pm, idx.reshape(bs, -1), scale, shift,
                                                        code[0], code[1], pixel_major=pixel_major, t_point_major=True)
                     return y if pixel_major else y.view(bs, -1, hr, wr)
-                t = ops.wx(wb, pre_layer(p_emb0).reshape(bs, wb.shape[1], -1))           # [B,Cout,n'] at the points
+                pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
+                if settings.USE_POINTWISE:
+                    t = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"))   # [B,Cout,n'] at the points
+                else:
+                    t = ops.wx(wb, pp)
                 if c == 64 and wa.shape[0] == 64:
                     # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
@@ -214,7 +222,7 @@ class FFB6DEmb(nn.Module):
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
             r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
-            p_emb = self.ds_fuse_r2p_fuse_layers[i_ds](torch.cat((p_emb0, r2p_emb), dim=1))
+            p_emb = self.ds_fuse_r2p_fuse_layers[i_ds].forward_segs([p_emb0, r2p_emb])       # over cat(p_emb0, r2p_emb), never formed
             ds_emb.append(p_emb)
 
         n_up = len(self.rndla_up_stages)
@@ -223,18 +231,17 @@ class FFB6DEmb(nn.Module):
             rgb_emb0 = self.cnn_up_stages[i_up](rgb_emb)
             bs, c, hr, wr = rgb_emb0.size()
 
-            f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])
-            p_emb0 = self.rndla_up_stages[i_up](torch.cat([ds_emb[-i_up - 2], f_interp_i], dim=1))
+            # decoder layer over cat(skip, nearest_interpolation(p_emb)): the interpolation is the second segment's index
+            p_emb0 = self.rndla_up_stages[i_up].forward_segs([ds_emb[-i_up - 2], (p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])])
 
             rgb_emb = self._p2r_fuse(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], rgb_emb0, p_emb0,
                                      inputs["p2r_up_nei_idx%d" % i_up], pixel_major=sparse_final and i_up == n_up - 2)
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_up_nei_idx%d" % i_up])
             r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)
-            p_emb = self.up_fuse_r2p_fuse_layers[i_up](torch.cat((p_emb0, r2p_emb), dim=1))
+            p_emb = self.up_fuse_r2p_fuse_layers[i_up].forward_segs([p_emb0, r2p_emb])
 
-        f_interp_i = self.nearest_interpolation(p_emb, inputs["cld_interp_idx0"])
-        p_emb = self.rndla_up_stages[n_up - 1](torch.cat([ds_emb[0], f_interp_i], dim=1)).squeeze(-1)
+        p_emb = self.rndla_up_stages[n_up - 1].forward_segs([ds_emb[0], (p_emb, inputs["cld_interp_idx0"])]).squeeze(-1)
         if sparse_final:
             # the last stage (up_3 + final) is a per-pixel function of a 3x3 neighbourhood and only the N `choose` pixels of its
             # full-resolution output are kept (reference ffb6d.py:266-285): evaluate it there, on the pixel-major fused map

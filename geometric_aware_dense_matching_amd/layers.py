@@ -10,7 +10,7 @@ Two flavours exist in the reference and both are needed:
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, settings
 
 
 def fused_eval(x, module):
@@ -84,8 +84,74 @@ def train_act_code(act):
 class _FusedConvMixin:
     _bn_name = None
 
+    def _pointwise_params(self):
+        """(W^T f32[Cin,Cout], scale, shift, act, slope) of this conv(+BN)(+activation) for ops.pointwise, cached until a parameter
+        changes; None when the layer is not a plain 1x1 convolution with an activation the kernel knows."""
+        conv = self.conv
+        if any(k != 1 for k in conv.kernel_size) or any(st != 1 for st in conv.stride) or conv.groups != 1 or any(p != 0 for p in conv.padding):
+            return None
+        code = act_code(getattr(self, "activation", None))
+        if code is None:
+            return None
+        bnw = getattr(self, self._bn_name, None)
+        deps = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+        if bnw is not None:
+            deps += [bnw.bn.weight, bnw.bn.bias, bnw.bn.running_mean, bnw.bn.running_var]
+        key = tuple((t._version, t.data_ptr()) for t in deps)
+        cache = self.__dict__.get("_gdm_pw")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                wt = conv.weight.reshape(conv.weight.shape[0], -1).t().contiguous()
+                if bnw is not None:
+                    scale, shift = folded_bn(bnw.bn, conv.bias)
+                else:
+                    scale, shift = None, (conv.bias.detach().contiguous() if conv.bias is not None else None)
+            cache = (key, wt, scale, shift)
+            self.__dict__["_gdm_pw"] = cache
+        return cache[1], cache[2], cache[3], code[0], code[1]
+
+    def forward_segs(self, segs, res=None, act=None):
+        """The layer over cat(segs, dim=1) WITHOUT forming the concat (eval: one ops.pointwise launch).  segs: list of
+        x [B,C,n(,1)] or (x [B,C,n_src(,1)], idx [B,n(,1)]) -- an indexed segment is x gathered at idx (nearest interpolation).
+        res = (another _FusedConvMixin layer without activation, its input segment): its output is added before the activation.
+        act = (ops.ACT_*, slope) replaces the layer's own activation (the activation after a residual sum).  Returns [B,Cout,n,1]."""
+        first = segs[0] if torch.is_tensor(segs[0]) else segs[0][0]
+        pw = self._pointwise_params() if (settings.USE_POINTWISE and fused_eval(first, self)) else None
+        rpw = None
+        if res is not None and pw is not None:
+            rpw = res[0]._pointwise_params()
+            if rpw is None or rpw[3] != ops.ACT_NONE:
+                pw = None
+        if pw is None:
+            xs = []
+            for sp in segs:
+                if torch.is_tensor(sp):
+                    xs.append(sp if sp.dim() == 4 else sp.unsqueeze(3))
+                else:
+                    xs.append(ops.gather_nn(sp[0], sp[1]).unsqueeze(3))
+            y = self(torch.cat(xs, dim=1) if len(xs) > 1 else xs[0])
+            if res is not None:
+                rx = res[1]
+                y = y + res[0](rx if rx.dim() == 4 else rx.unsqueeze(3))
+            if act is not None and act[0] != ops.ACT_NONE:
+                y = torch.relu(y) if act[0] == ops.ACT_RELU else torch.nn.functional.leaky_relu(y, negative_slope=act[1])
+            return y
+        wt, scale, shift, a_code, slope = pw
+        if act is not None:
+            a_code, slope = act
+        r = None
+        if rpw is not None:
+            r = (res[1], rpw[0], rpw[1], rpw[2])
+        return ops.pointwise(list(segs), wt, scale, shift, a_code, slope, res=r).unsqueeze(3)
+
     def forward(self, x):
         bnw = getattr(self, self._bn_name, None)
+        if settings.USE_POINTWISE and fused_eval(x, self) and x.dim() in (3, 4):
+            pw = self._pointwise_params()
+            if pw is not None:
+                B = x.shape[0]
+                y = ops.pointwise([x.reshape(B, x.shape[1], -1)], pw[0], pw[1], pw[2], pw[3], pw[4])
+                return y.view(B, -1, *x.shape[2:])
         if bnw is not None and fused_eval(x, self):
             code = act_code(getattr(self, "activation", None))
             if code is not None and self.conv.bias is None:

@@ -31,7 +31,7 @@ KEEP = "_pyramid_keep"            # key of the buffers the build keeps alive wit
 PYR_STREAM = 2                    # side-stream number of an overlapped build (its own: the point branch forks onto 0, the mesh branch onto 1)
 
 
-def build_pyramid(cld, dpt_xyz, overlap=False):
+def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
     """overlap=True (inference, settings.USE_SIDE_STREAMS with "pyr" in SIDE_PARTS): the searches are enqueued on a side stream of
     their own, so that the image trunk's first stages -- which need no indices -- run beside them; the returned dict then carries
     the event EVERY consuming stream must wait for under READY (FFB6DEmb.forward does, on the main stream and on the point
@@ -43,10 +43,12 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
     if overlap and settings.USE_SIDE_STREAMS and "pyr" in settings.SIDE_PARTS:
         with ops.fork(cld.device, PYR_STREAM) as f:
             f.use(cld, dpt_xyz)
-            pyr = build_pyramid(cld, dpt_xyz)
+            keep = []
+            pyr = build_pyramid(cld, dpt_xyz, _keep=keep)
             ev = torch.cuda.Event()
             ev.record(f.side)
-        pyr[READY] = ev
+        pyr[READY] = ev                 # the only two non-tensor entries, and only of an overlapped build
+        pyr[KEEP] = keep
         return pyr
     B, N, _ = cld.shape
     S = dpt_xyz.shape[1]
@@ -71,11 +73,11 @@ def build_pyramid(cld, dpt_xyz, overlap=False):
         pts, px = levels[3 - i], grids[RGB_UP_SR[i]]
         jobs += [(px, pts, K_NEI, S // RGB_UP_SR[i]), (pts, px, 1)]
         names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
-    keep = [grids[sc] for sc in (2, 4, 8)]
-    outs = ops.knn_jobs(jobs, B, keep_workspace=keep)
+    if _keep is not None:
+        _keep += [grids[sc] for sc in (2, 4, 8)]
+    outs = ops.knn_jobs(jobs, B, keep_workspace=_keep)
 
     pyr = dict(zip(names, outs))
-    pyr[KEEP] = keep
     for i in range(4):
         # prefix views are batch-strided; every consumer (two LFA stage launches per level, the pooling gather) wants them dense,
         # so they are made contiguous once here instead of once per use

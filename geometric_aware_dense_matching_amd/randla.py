@@ -99,6 +99,9 @@ class DilatedResBlock(nn.Module):
     def forward(self, feature, xyz, neigh_idx):
         f_pc = self.mlp1(feature)
         f_pc = self.lfa(xyz, f_pc, neigh_idx)
+        if fused_eval(feature, self) and settings.USE_POINTWISE:
+            # lrelu(bn(mlp2(f_pc)) + bn(shortcut(feature))): both 1x1 layers, both folded BatchNorms, the sum and the activation in ONE launch
+            return self.mlp2.forward_segs([f_pc], res=(self.shortcut, feature), act=(ops.ACT_LEAKY, 0.2))
         if fused_eval(feature, self):
             sa, ba = folded_bn(self.mlp2.bn.bn)
             sr, br = folded_bn(self.shortcut.bn.bn)

@@ -444,6 +444,27 @@ int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, in
                         const float* const* scale, const float* const* shift, const int* act, int feat_layer, int res_layer,
                         const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * One per-point (1x1) layer in a single launch (inference): concat-free, BatchNorm / bias / activation / residual branch folded in.
+ * Replaces torch.cat -> Conv1d/Conv2d(1x1) -> BatchNorm -> activation of /root/reference/models/pytorch_utils.py:70-124 and
+ * models/RandLA/pytorch_utils.py:34-99, the tail lrelu(mlp2(f) + shortcut(x)) of Dilated_res_block (RandLANet.py:685-688), the
+ * fusion layers over cat(point, pooled pixel) features (ffb6d.py:224-231,259-265) and the decoder layers over
+ * cat(skip, nearest_interpolation(deeper)) (ffb6d.py:246-250,268-272; the interpolation = `idx` of the second segment).
+ *   out[b, out_c0 + c, i] = act( scale[c] * sum_k wt[k][c] * X[b,k,i] + shift[c]  (+ rscale[c] * sum_k rwt[k][c] * Xr[b,k,i] + rshift[c]) )
+ * X = the channels of segs[0] followed by those of segs[1] (the concat, never formed).  A segment is f32[B,C,n_src] channel-major
+ * (point_major 0) or f32[B*n_src,C] (point_major 1), read at column i (n_src == n) or at idx[b*n + i] (i32, any n_src).
+ * wt f32[K,Cout] TRANSPOSED weight, K = sum of the segments' C; scale / shift / rscale / rshift f32[Cout] or NULL (1 / 0).
+ * act: 0 none, 1 ReLU, 2 leaky ReLU (slope).  out f32[B,out_C,n] (point_major 0) or f32[B*n,out_C] (1), 16-byte aligned;
+ * channels [out_c0, out_c0 + Cout) of it are written.  fp32 FMAs, ascending-k summation. */
+typedef struct {
+    const float* x;
+    const int32_t* idx;
+    int32_t C, n_src, point_major;
+} gdm_pw_seg;
+int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
+                      const gdm_pw_seg* rseg, const float* rwt, const float* rscale, const float* rshift,
+                      int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

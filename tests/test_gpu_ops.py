@@ -675,3 +675,62 @@ def test_affine_relu_maxpool_equals_modules(ops, B, C, H, W):
     got = ops.affine_relu_maxpool(x, scale, shift)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,n,cs,cout,n_src,res_c,pm", [
+    (16, 2048, (8,), 16, None, None, False),          # DilatedResBlock(8, 32).mlp1
+    (16, 2048, (32,), 64, None, 8, False),            # its tail: lrelu(bn(mlp2) + bn(shortcut))
+    (16, 8, (512, 512), 512, None, None, False),      # deepest r2p fuse over cat(p_emb0, r2p_emb): 8 points per crop
+    (2, 512, (64, 128), 64, 128, None, False),        # decoder over cat(skip, nearest_interpolation(deeper))
+    (3, 37, (5, 3), 7, 11, 6, False),                 # ragged everything
+    (4, 512, (64,), 64, None, None, True),            # point-major product for the 64-channel fusion kernel
+    (2, 130, (70,), 130, None, None, True),
+])
+def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, res_c, pm):
+    """ops.pointwise (gdm_pointwise_hip) == cat -> 1x1 conv -> affine (folded BN) -> (+ residual branch) -> activation in fp64 torch,
+    to fp32 rounding of a K-term dot product (1e-5 relative to the output scale); indexed segment = nearest interpolation."""
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + n)
+    xs, segs = [], []
+    for j, c in enumerate(cs):
+        if j == 1 and n_src is not None:
+            src = torch.randn(B, c, n_src, generator=g).cuda()
+            idx = torch.randint(0, n_src, (B, n, 1), generator=g).int().cuda()
+            xs.append(torch.gather(src, 2, idx.view(B, 1, n).expand(B, c, n).long()))
+            segs.append((src, idx))
+        else:
+            x = torch.randn(B, c, n, generator=g).cuda()
+            xs.append(x)
+            segs.append(x.unsqueeze(3) if j == 0 else x)
+    K = sum(cs)
+    w = (torch.randn(cout, K, generator=g) / K ** 0.5).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    want = torch.einsum("ok,bkn->bon", w.double(), torch.cat(xs, 1).double()) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1)
+    res = None
+    if res_c is not None:
+        xr = torch.randn(B, res_c, n, generator=g).cuda()
+        wr = torch.randn(cout, res_c, generator=g).cuda()
+        rs, rb = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+        want = want + torch.einsum("ok,bkn->bon", wr.double(), xr.double()) * rs.double().view(1, -1, 1) + rb.double().view(1, -1, 1)
+        res = (xr, wr.t().contiguous(), rs, rb)
+    want = torch.where(want > 0, want, want * 0.2)
+    got = ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, res=res, point_major=pm)
+    if pm:
+        assert got.shape == (B, n, cout)
+        got = got.transpose(1, 2)
+    tol = 1e-5 * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < tol
+    # channel-offset output: the layer writes channels [c0, c0 + cout) of a wider tensor and nothing else
+    if not pm:
+        wide = torch.full((B, cout + 9, n), 7.0, device="cuda")
+        ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, res=res, out=wide, out_c0=5)
+        assert torch.equal(wide[:, 5:5 + cout], got) and bool((wide[:, :5] == 7).all()) and bool((wide[:, 5 + cout:] == 7).all())
+
+
+def test_pointwise_rejects_bad_arguments(ops):
+    x = torch.randn(2, 8, 64, device="cuda")
+    with pytest.raises(ValueError):
+        ops.pointwise([x], torch.randn(9, 4, device="cuda"))                     # weight rows != channels
+    with pytest.raises(ValueError):
+        ops.pointwise([x, torch.randn(2, 8, 32, device="cuda")], torch.randn(16, 4, device="cuda"))   # segments disagree on n
+    with pytest.raises(RuntimeError):
+        ops.pointwise([x.cpu()], torch.randn(8, 4))                              # no CPU path
