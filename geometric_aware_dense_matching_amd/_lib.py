@@ -123,11 +123,10 @@ SIGNATURES = {
 
 class PwSeg(ctypes.Structure):
     """gdm_pw_seg (include/gdm.h)."""
-    _fields_ = [("x", _vp), ("idx", _vp), ("C", ctypes.c_int32), ("n_src", ctypes.c_int32), ("point_major", ctypes.c_int32)]
+    _fields_ = [("x", _vp), ("idx", _vp), ("C", ctypes.c_int32), ("n_src", ctypes.c_int32)]
 
 
-SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, ctypes.POINTER(PwSeg), _vp, _vp, _vp,
-                                        _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
+SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 
 _lib = None
 

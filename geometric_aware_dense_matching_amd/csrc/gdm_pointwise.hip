@@ -5,140 +5,213 @@
 //   Dilated_res_block's tail  lrelu(mlp2(f) + shortcut(x))            /root/reference/models/RandLA/RandLANet.py:685-688,
 //   the fusion layers over cat(point features, pooled pixel features)   /root/reference/models/ffb6d.py:224-231,259-265,
 //   the decoder layers over cat(skip, nearest_interpolation(deeper))    /root/reference/models/ffb6d.py:246-250,268-272
-// by ONE launch:   out[b,:,i] = act( scale * (W . [x0 ; x1][b,:,i]) + shift  (+ rscale * (Wr . xr[b,:,i]) + rshift) )
+// by ONE launch:   out[b,:,i] = act( scale * (W . [x0 ; x1 ; x2][b,:,i]) + shift )
 // where every input segment is a channel-major tensor f32[B,C,n_src] read either in place (n_src == n) or through a per-point
-// index idx[b,i] (the nearest-neighbour interpolation of ffb6d.py:148-163 folded into the load), or a point-major tensor f32[B*n,C].
-// The concat is never formed: the K loop walks the segments in order, so the sum runs over the same channels in the same order.
+// index idx[b,i] (the nearest-neighbour interpolation of ffb6d.py:148-163 folded into the load).  The concat is never formed: the
+// K loop walks the segments in order.  The residual tail is the same layer over [f ; x] with the two folded BatchNorm scales
+// multiplied into the two weight blocks and the shifts added (done once, on the host side of the module cache).
 //
 // These layers are tiny (8..1024 channels at 128..32768 points: < 2 GFLOP for all ~40 of them per step) and the step is bound by
-// their launch count, not their arithmetic: fp32 FMAs (exact fp32 products, ascending-k summation), a 64-point x 64-channel tile
-// per 256-thread workgroup, operands staged through LDS in 16-deep K chunks, coalesced along the points.
+// their launch count and their latency, not their arithmetic: fp32 FMAs (exact fp32 products, ascending-k summation per partial).
+// A wave owns a 64-point x 16-channel tile (lane = 4 points x 4 channels); a workgroup is NW such waves arranged as NW/KS channel
+// groups x KS parts of the K axis: (NW, KS) = (4, 1) where the points alone fill the chip, (16, 4) and (16, 8) for the deep levels
+// (128..2048 points, K up to 1024), whose only parallelism is K: sixteen waves per CU hide each other's latencies, and the KS
+// partial sums are added in fixed order through LDS.  Operands are staged through LDS in 16-deep K chunks, coalesced along the
+// points, with the next chunk's global loads in flight during the FMAs.
 #include "gdm_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int PT = 64, CT = 64, KT = 16, XS = 68;       // XS: padded row of the x tile (keeps float4 reads aligned, spreads banks)
+constexpr int PT = 64, XS = 68;       // XS: padded row of the x tile (keeps float4 reads aligned, spreads banks)
+constexpr int MAXSEG = 3;
 
 struct PwSegDev {
     const float* x;
     const int32_t* idx;
-    int C, n_src, point_major;
+    int C, n_src;
 };
 
 struct PwArgs {
-    PwSegDev seg[2];
+    PwSegDev seg[MAXSEG];
     int nseg;
     const float* wt;          // [K][Cout], K = sum of the segments' channels, rows in segment order
     const float* scale;       // [Cout] or NULL (1)
     const float* shift;       // [Cout] or NULL (0)
-    PwSegDev rseg;            // residual branch (x == NULL: none)
-    const float* rwt;         // [Cr][Cout]
-    const float* rscale;
-    const float* rshift;
     float* out;
-    int n, Cout, outC, out_c0, point_major, act;
+    int n, Cout, outC, out_c0, point_major, act, K;
     float slope;
     long total;               // B * n
 };
 
-__device__ __forceinline__ void pw_gemm(const PwSegDev& s, const float* __restrict__ wt, int Cout, int n, long g0, long total,
-                                        int c0, float (*xs)[XS], float (*ws)[CT], float (&acc)[4][4])
+// address of point (crop b, column i; flat index g) in a channel-major segment: scalars in, so that nothing takes the address of
+// the kernel-argument block (which would copy it to scratch memory)
+__device__ __forceinline__ const float* seg_column(const float* x, const int32_t* idx, int C, int n_src, long b, int i, long g)
 {
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int C = s.C;
-    // this thread's column of the x tile
-    const float* xb = nullptr;
-    long xstride = 0;
-    int lp, lk;
-    if (!s.point_major) {
-        lp = tid & 63;
-        lk = tid >> 6;                                    // 0..3, rows lk + 4 r
-        const long g = g0 + lp;
-        if (g < total) {
-            const long b = g / n;
-            const int i = (int)(g - b * n);
-            int col = i;
-            if (s.idx) col = min(max(s.idx[g], 0), s.n_src - 1);
-            xb = s.x + b * (long)C * s.n_src + col;
-            xstride = s.n_src;
-        }
-    } else {
-        lp = tid >> 4;                                    // 0..15, points lp + 16 r
-        lk = tid & 15;
-    }
-    const int wc = c0 + (tid & 63);
-    const int wk = tid >> 6;
-    for (int k0 = 0; k0 < C; k0 += KT) {
-        if (!s.point_major) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + lk + 4 * r;
-                xs[lk + 4 * r][lp] = (xb && k < C) ? xb[(long)k * xstride] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long g = g0 + lp + 16 * r;
-                const int k = k0 + lk;
-                float v = 0.f;
-                if (g < total && k < C) {
-                    long row = g;
-                    if (s.idx) {
-                        const long b = g / n;
-                        row = b * s.n_src + min(max(s.idx[g], 0), s.n_src - 1);
-                    }
-                    v = s.x[row * C + k];
-                }
-                xs[lk][lp + 16 * r] = v;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = k0 + wk + 4 * r;
-            ws[wk + 4 * r][tid & 63] = (k < C && wc < Cout) ? wt[(long)k * Cout + wc] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KT; ++kk) {
-            const float4 xv = *reinterpret_cast<const float4*>(&xs[kk][tx * 4]);
-            const float4 wv = *reinterpret_cast<const float4*>(&ws[kk][ty * 4]);
-            acc[0][0] = fmaf(wv.x, xv.x, acc[0][0]); acc[0][1] = fmaf(wv.x, xv.y, acc[0][1]);
-            acc[0][2] = fmaf(wv.x, xv.z, acc[0][2]); acc[0][3] = fmaf(wv.x, xv.w, acc[0][3]);
-            acc[1][0] = fmaf(wv.y, xv.x, acc[1][0]); acc[1][1] = fmaf(wv.y, xv.y, acc[1][1]);
-            acc[1][2] = fmaf(wv.y, xv.z, acc[1][2]); acc[1][3] = fmaf(wv.y, xv.w, acc[1][3]);
-            acc[2][0] = fmaf(wv.z, xv.x, acc[2][0]); acc[2][1] = fmaf(wv.z, xv.y, acc[2][1]);
-            acc[2][2] = fmaf(wv.z, xv.z, acc[2][2]); acc[2][3] = fmaf(wv.z, xv.w, acc[2][3]);
-            acc[3][0] = fmaf(wv.w, xv.x, acc[3][0]); acc[3][1] = fmaf(wv.w, xv.y, acc[3][1]);
-            acc[3][2] = fmaf(wv.w, xv.z, acc[3][2]); acc[3][3] = fmaf(wv.w, xv.w, acc[3][3]);
-        }
-        __syncthreads();
-    }
+    int col = i;
+    if (idx) col = min(max(idx[g], 0), n_src - 1);
+    return x + b * (long)C * n_src + col;
 }
 
-__global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a)
+template <int NW, int KS, bool VEC>
+__global__ __launch_bounds__(NW * 64) void pointwise_kernel(const PwArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float xs[KT][XS];
-    __shared__ __attribute__((aligned(16))) float ws[KT][CT];
+    constexpr int NCG = NW / KS;                 // channel groups (of 16) per workgroup
+    constexpr int KT = 16;                       // K rows per chunk and K part
+    constexpr int XL = KT / NCG;                 // x rows each wave loads per chunk (the NCG waves of a K part share its x tile)
+    constexpr int WL = KT / 4;                   // w rows (of 16 channels) each lane loads per chunk
+    static_assert(NCG >= 1 && NCG <= KT && KT % NCG == 0, "tile arrangement");
+    __shared__ __attribute__((aligned(16))) float xs[KS][KT][XS];
+    __shared__ __attribute__((aligned(16))) float ws[NW][KT][16];
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? NW : 1][16][64];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cg = wave / KS, kp = wave % KS;
+    const int tx = lane & 15, ty = lane >> 4;
     const long g0 = (long)blockIdx.x * PT;
-    const int c0 = (int)blockIdx.y * CT;
-    const int n = a.n, Cout = a.Cout;
+    const int c0 = ((int)blockIdx.y * NCG + cg) * 16;
+    const int n = a.n, Cout = a.Cout, K = a.K;
+    const int kpart = (((K + KS - 1) / KS + KT - 1) / KT) * KT;
+    const int kbeg = kp * kpart;
+    const int nchunk = kpart / KT;
 
-    float acc[4][4], racc[4][4];
+    // this lane's point column in every segment.  Every address formed below is a valid one (points past the end read point 0,
+    // rows past K read row K-1 and are zeroed by a select on a wave-uniform condition, channels past Cout read channel Cout-1):
+    // the loads carry no branch, so a chunk's loads are all in flight together; what the out-of-range lanes compute is never stored
+    const float *xb0, *xb1, *xb2;                 // scalars, not an array: a dynamically indexed array would live in scratch memory
+    long xs0, xs1, xs2;
+    int ce0, ce1;
+    {
+        // scalar path: lane = one point of the tile, rows uniform over the wave.  VEC path (no index, n % 4 == 0, Cout % 4 == 0):
+        // lane = four consecutive points (lane & 15) of row (lane >> 4): one 16-byte load per lane fetches four rows per wave
+        // instruction -- a wave-wide dword load costs the texture path as much as a dwordx4 one, and it is that path, not the FMAs,
+        // that bounds the deep layers
+        const long g = min(g0 + (VEC ? (lane & 15) * 4 : lane), a.total - (VEC ? 4 : 1));
+        const long b = g / n;
+        const int i = (int)(g - b * n);
+        xb0 = seg_column(a.seg[0].x, a.seg[0].idx, a.seg[0].C, a.seg[0].n_src, b, i, g);
+        xs0 = a.seg[0].n_src;
+        xb1 = xb2 = xb0;                          // absent segments alias segment 0 (never selected: their range of k is empty)
+        xs1 = xs2 = xs0;
+        ce0 = a.seg[0].C;
+        ce1 = ce0;
+        if (a.nseg > 1) {
+            xb1 = seg_column(a.seg[1].x, a.seg[1].idx, a.seg[1].C, a.seg[1].n_src, b, i, g);
+            xs1 = a.seg[1].n_src;
+            ce1 = ce0 + a.seg[1].C;
+        }
+        if (a.nseg > 2) {
+            xb2 = seg_column(a.seg[2].x, a.seg[2].idx, a.seg[2].C, a.seg[2].n_src, b, i, g);
+            xs2 = a.seg[2].n_src;
+        }
+    }
+    const float* const wtp = a.wt;
+    // segment of row k by ARITHMETIC on 0/1 masks, not by selects: the compiler turns a chain of selects over the three
+    // (pointer, stride) pairs into a table in scratch memory indexed per load
+    const long e1 = (const char*)xb1 - (const char*)xb0, e2 = (const char*)xb2 - (const char*)xb1;
+    const long sd1 = xs1 - xs0, sd2 = xs2 - xs1;
+    const int cd1 = ce0, cd2 = ce1 - ce0;
+    auto x_addr = [&](int k) -> const float* {   // address of row min(k, K-1) in this lane's column (RAW: rows past K are zeroed where
+        const int kc = min(k, K - 1);             // the value is stored to LDS -- a select here would sit right behind the load and
+        const long t1 = -(long)(kc >= ce0), t2 = -(long)(kc >= ce1);              // make the prefetch wait); t = 0 or all ones
+        const int kl = kc - (cd1 & (int)t1) - (cd2 & (int)t2);
+        const long str = xs0 + (sd1 & t1) + (sd2 & t2);
+        const float* base = (const float*)((const char*)xb0 + (e1 & t1) + (e2 & t2));
+        return base + (long)kl * str;
+    };
+    // x rows of this wave in a chunk: scalar XL rows cg + NCG r (uniform); VEC XL / 4 loads of rows cg XL + 4 j + (lane >> 4)
+    // w tile 16 x 16 of this wave: scalar rows (lane >> 4) + 4 r, channel lane & 15; VEC row lane >> 2, channels 4 (lane & 3) ..
+    constexpr int XV = VEC ? XL / 4 : XL;
+    constexpr int WV = VEC ? KT / 16 : WL;
+    static_assert(!VEC || (XL % 4 == 0 && KT % 16 == 0), "vector loads cover 4 x rows / 16 w rows per instruction");
+    const int wc = VEC ? min(c0 + (lane & 3) * 4, Cout - 4) : min(c0 + (lane & 15), Cout - 1);
+    auto x_row = [&](int r) -> int { return VEC ? cg * XL + 4 * r + (lane >> 4) : cg + NCG * r; };
+    auto w_row = [&](int r) -> int { return VEC ? 16 * r + (lane >> 2) : (lane >> 4) + 4 * r; };
+
+    float acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[j][q] = racc[j][q] = 0.f;
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
 
-    const float* wt = a.wt;
-    for (int s = 0; s < a.nseg; ++s) {
-        pw_gemm(a.seg[s], wt, Cout, n, g0, a.total, c0, xs, ws, acc);
-        wt += (long)a.seg[s].C * Cout;
+    float4 xr[XV], wr[WV];                        // scalar path: .x only
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < XV; ++r) {
+            const float* p = x_addr(k0 + x_row(r));
+            if (VEC) xr[r] = *reinterpret_cast<const float4*>(p);
+            else xr[r].x = *p;
+        }
+#pragma unroll
+        for (int r = 0; r < WV; ++r) {
+            const float* p = wtp + (long)min(k0 + w_row(r), K - 1) * Cout + wc;
+            if (VEC) wr[r] = *reinterpret_cast<const float4*>(p);
+            else wr[r].x = *p;
+        }
+    };
+    fetch(kbeg);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int kc0 = kbeg + ch * KT;
+#pragma unroll
+        for (int r = 0; r < XV; ++r) {
+            const bool in = kc0 + x_row(r) < K;
+            if (VEC) *reinterpret_cast<float4*>(&xs[kp][x_row(r)][(lane & 15) * 4]) = in ? xr[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            else xs[kp][x_row(r)][lane] = in ? xr[r].x : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < WV; ++r) {
+            const bool in = kc0 + w_row(r) < K;
+            if (VEC) *reinterpret_cast<float4*>(&ws[wave][w_row(r)][(lane & 3) * 4]) = in ? wr[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            else ws[wave][w_row(r)][lane & 15] = in ? wr[r].x : 0.f;
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) fetch(kbeg + (ch + 1) * KT);   // next chunk's loads fly during the FMAs below
+        float4 xv[2][4], wv[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[0][u] = *reinterpret_cast<const float4*>(&xs[kp][u][tx * 4]);
+            wv[0][u] = *reinterpret_cast<const float4*>(&ws[wave][u][ty * 4]);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < KT / 4; ++k4) {
+            const int cur = k4 & 1, nxt = cur ^ 1;
+            if (k4 + 1 < KT / 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[nxt][u] = *reinterpret_cast<const float4*>(&xs[kp][(k4 + 1) * 4 + u][tx * 4]);
+                    wv[nxt][u] = *reinterpret_cast<const float4*>(&ws[wave][(k4 + 1) * 4 + u][ty * 4]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 x4 = xv[cur][u], w4 = wv[cur][u];
+                acc[0][0] = fmaf(w4.x, x4.x, acc[0][0]); acc[0][1] = fmaf(w4.x, x4.y, acc[0][1]);
+                acc[0][2] = fmaf(w4.x, x4.z, acc[0][2]); acc[0][3] = fmaf(w4.x, x4.w, acc[0][3]);
+                acc[1][0] = fmaf(w4.y, x4.x, acc[1][0]); acc[1][1] = fmaf(w4.y, x4.y, acc[1][1]);
+                acc[1][2] = fmaf(w4.y, x4.z, acc[1][2]); acc[1][3] = fmaf(w4.y, x4.w, acc[1][3]);
+                acc[2][0] = fmaf(w4.z, x4.x, acc[2][0]); acc[2][1] = fmaf(w4.z, x4.y, acc[2][1]);
+                acc[2][2] = fmaf(w4.z, x4.z, acc[2][2]); acc[2][3] = fmaf(w4.z, x4.w, acc[2][3]);
+                acc[3][0] = fmaf(w4.w, x4.x, acc[3][0]); acc[3][1] = fmaf(w4.w, x4.y, acc[3][1]);
+                acc[3][2] = fmaf(w4.w, x4.z, acc[3][2]); acc[3][3] = fmaf(w4.w, x4.w, acc[3][3]);
+            }
+        }
+        __syncthreads();
     }
-    const bool has_res = a.rseg.x != nullptr;
-    if (has_res) pw_gemm(a.rseg, a.rwt, Cout, n, g0, a.total, c0, xs, ws, racc);
+    if (KS > 1) {                                  // partial sums of the K parts, added in the fixed order 0, 1, .., KS-1
+        if (kp != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave][j * 4 + q][lane] = acc[j][q];
+        }
+        __syncthreads();
+        if (kp != 0) return;
+        for (int p = 1; p < KS; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] += red[cg * KS + p][j * 4 + q][lane];
+    }
 
     const long p0 = g0 + tx * 4;
     float v[4][4];
@@ -148,19 +221,16 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a)
         const bool live = c < Cout;
         const float sc = (live && a.scale) ? a.scale[c] : 1.f;
         const float sh = (live && a.shift) ? a.shift[c] : 0.f;
-        const float rs = (live && has_res && a.rscale) ? a.rscale[c] : 1.f;
-        const float rb = (live && has_res && a.rshift) ? a.rshift[c] : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float y = fmaf(acc[j][q], sc, sh);
-            if (has_res) y += fmaf(racc[j][q], rs, rb);
             if (a.act == 1) y = fmaxf(y, 0.f);
             else if (a.act == 2) y = y > 0.f ? y : y * a.slope;
             v[j][q] = y;
         }
     }
     if (a.point_major) {
-        // out[p][out_c0 + c]: the thread's four channels are contiguous
+        // out[p][out_c0 + c]: the lane's four channels are contiguous
         const int c = c0 + ty * 4;
         const bool vec = (a.outC % 4 == 0) && (a.out_c0 % 4 == 0) && (c + 3 < Cout);
 #pragma unroll
@@ -201,37 +271,34 @@ bool seg_ok(const gdm_pw_seg& s, int n)
     return s.x && s.C >= 1 && s.n_src >= 1 && (s.idx || s.n_src == n);
 }
 
-PwSegDev to_dev(const gdm_pw_seg& s) { return PwSegDev{s.x, s.idx, s.C, s.n_src, s.point_major}; }
-
 } // namespace
 
 extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
-                                 const gdm_pw_seg* rseg, const float* rwt, const float* rscale, const float* rshift,
                                  int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major,
                                  void* stream)
 {
     GDM_CHECK_ARG(segs && wt && out, "gdm_pointwise_hip: NULL pointer");
-    GDM_CHECK_ARG(nseg >= 1 && nseg <= 2, "gdm_pointwise_hip: nseg=%d not in [1,2]", nseg);
+    GDM_CHECK_ARG(nseg >= 1 && nseg <= MAXSEG, "gdm_pointwise_hip: nseg=%d not in [1,%d]", nseg, MAXSEG);
     GDM_CHECK_ARG(B >= 1 && n >= 1 && Cout >= 1, "gdm_pointwise_hip: bad shape B=%d n=%d Cout=%d", B, n, Cout);
     GDM_CHECK_ARG(out_c0 >= 0 && out_c0 + Cout <= out_C, "gdm_pointwise_hip: channels [%d, %d) outside the output's %d", out_c0,
                   out_c0 + Cout, out_C);
     GDM_CHECK_ARG(act >= 0 && act <= 2, "gdm_pointwise_hip: act=%d", act);
-    for (int s = 0; s < nseg; ++s)
-        GDM_CHECK_ARG(seg_ok(segs[s], n), "gdm_pointwise_hip: segment %d: NULL / empty, or n_src=%d != n=%d without an index", s,
-                      segs[s].n_src, n);
-    GDM_CHECK_ARG(!rseg || (seg_ok(*rseg, n) && rwt), "gdm_pointwise_hip: bad residual segment");
-    GDM_CHECK_ARG(((uintptr_t)out & 15) == 0, "gdm_pointwise_hip: out must be 16-byte aligned");
     PwArgs a;
+    a.K = 0;
+    for (int s = 0; s < MAXSEG; ++s) {
+        if (s < nseg) {
+            GDM_CHECK_ARG(seg_ok(segs[s], n), "gdm_pointwise_hip: segment %d: NULL / empty, or n_src=%d != n=%d without an index", s,
+                          segs[s].n_src, n);
+            a.seg[s] = PwSegDev{segs[s].x, segs[s].idx, segs[s].C, segs[s].n_src};
+            a.K += segs[s].C;
+        } else
+            a.seg[s] = PwSegDev{nullptr, nullptr, 0, 0};
+    }
+    GDM_CHECK_ARG(((uintptr_t)out & 15) == 0, "gdm_pointwise_hip: out must be 16-byte aligned");
     a.nseg = nseg;
-    a.seg[0] = to_dev(segs[0]);
-    a.seg[1] = nseg > 1 ? to_dev(segs[1]) : PwSegDev{nullptr, nullptr, 0, 0, 0};
     a.wt = wt;
     a.scale = scale;
     a.shift = shift;
-    a.rseg = rseg ? to_dev(*rseg) : PwSegDev{nullptr, nullptr, 0, 0, 0};
-    a.rwt = rwt;
-    a.rscale = rscale;
-    a.rshift = rshift;
     a.out = out;
     a.n = n;
     a.Cout = Cout;
@@ -242,8 +309,23 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
     a.slope = slope;
     a.total = (long)B * n;
     const long tiles = (a.total + PT - 1) / PT;
-    GDM_CHECK_ARG(tiles <= 0x7fffffffL && gdm_cdiv(Cout, CT) <= 65535, "gdm_pointwise_hip: grid too large");
-    dim3 grid((unsigned)tiles, gdm_cdiv(Cout, CT));
-    hipLaunchKernelGGL(pointwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    GDM_CHECK_ARG(tiles <= 0x7fffffffL, "gdm_pointwise_hip: grid too large");
+    // enough 64 x 64 tiles to fill the chip: four waves per workgroup, no K split.  Otherwise sixteen waves per workgroup share the
+    // K axis: 8 parts of two 16-channel groups (2x the workgroups) where K is deep, else 4 parts of four channel groups
+    const long base = tiles * gdm_cdiv(Cout, 64);
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = (n % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    for (int s = 0; s < nseg; ++s) vec = vec && !segs[s].idx && (((uintptr_t)segs[s].x & 15) == 0);
+    if (getenv("GDM_PW_NOVEC")) vec = false;
+#define GDM_PW_LAUNCH(NW, KS, COUT_PER_WG)                                                                                          \
+    do {                                                                                                                            \
+        const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, COUT_PER_WG));                                                              \
+        if (vec) hipLaunchKernelGGL((pointwise_kernel<NW, KS, true>), grid, dim3(NW * 64), 0, st, a);                               \
+        else hipLaunchKernelGGL((pointwise_kernel<NW, KS, false>), grid, dim3(NW * 64), 0, st, a);                                  \
+    } while (0)
+    if (base >= 256 || a.K < 64) GDM_PW_LAUNCH(4, 1, 64);
+    else if (a.K >= 256 && gdm_cdiv(Cout, 16) <= 65535) GDM_PW_LAUNCH(8, 8, 16);
+    else GDM_PW_LAUNCH(8, 2, 64);
+#undef GDM_PW_LAUNCH
     return gdm_launch_status("pointwise_kernel");
 }

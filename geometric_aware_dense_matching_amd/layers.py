@@ -110,19 +110,34 @@ class _FusedConvMixin:
             self.__dict__["_gdm_pw"] = cache
         return cache[1], cache[2], cache[3], code[0], code[1]
 
+    def _residual_params(self, other):
+        """This layer + `other` (both without activation) as ONE layer over cat(own input, other's input):
+        s1*(W1 x1) + b1 + s2*(W2 x2) + b2 = [s1*W1 | s2*W2] . [x1 ; x2] + (b1 + b2).  Cached on self."""
+        a, b = self._pointwise_params(), other._pointwise_params()
+        if a is None or b is None or a[3] != ops.ACT_NONE or b[3] != ops.ACT_NONE:
+            return None
+        cache = self.__dict__.get("_gdm_pw_res")
+        if cache is None or cache[0] is not a[0] or cache[1] is not b[0] or cache[2] is not a[1] or cache[3] is not b[1]:
+            with torch.no_grad():
+                def scaled(w, sc):
+                    return w if sc is None else w * sc.view(1, -1)
+                wt = torch.cat([scaled(a[0], a[1]), scaled(b[0], b[1])], dim=0).contiguous()
+                sh = [t for t in (a[2], b[2]) if t is not None]
+                shift = (sh[0] + sh[1]) if len(sh) == 2 else (sh[0] if sh else None)
+            cache = (a[0], b[0], a[1], b[1], wt, shift)
+            self.__dict__["_gdm_pw_res"] = cache
+        return cache[4], cache[5]
+
     def forward_segs(self, segs, res=None, act=None):
         """The layer over cat(segs, dim=1) WITHOUT forming the concat (eval: one ops.pointwise launch).  segs: list of
         x [B,C,n(,1)] or (x [B,C,n_src(,1)], idx [B,n(,1)]) -- an indexed segment is x gathered at idx (nearest interpolation).
-        res = (another _FusedConvMixin layer without activation, its input segment): its output is added before the activation.
+        res = (another _FusedConvMixin layer without activation, its input): its output is added before the activation.
         act = (ops.ACT_*, slope) replaces the layer's own activation (the activation after a residual sum).  Returns [B,Cout,n,1]."""
         first = segs[0] if torch.is_tensor(segs[0]) else segs[0][0]
-        pw = self._pointwise_params() if (settings.USE_POINTWISE and fused_eval(first, self)) else None
-        rpw = None
-        if res is not None and pw is not None:
-            rpw = res[0]._pointwise_params()
-            if rpw is None or rpw[3] != ops.ACT_NONE:
-                pw = None
-        if pw is None:
+        fused = settings.USE_POINTWISE and fused_eval(first, self)
+        pw = self._pointwise_params() if fused else None
+        rp = self._residual_params(res[0]) if (pw is not None and res is not None) else None
+        if pw is None or (res is not None and rp is None):
             xs = []
             for sp in segs:
                 if torch.is_tensor(sp):
@@ -139,10 +154,12 @@ class _FusedConvMixin:
         wt, scale, shift, a_code, slope = pw
         if act is not None:
             a_code, slope = act
-        r = None
-        if rpw is not None:
-            r = (res[1], rpw[0], rpw[1], rpw[2])
-        return ops.pointwise(list(segs), wt, scale, shift, a_code, slope, res=r).unsqueeze(3)
+        segs = list(segs)
+        if res is not None:
+            wt, shift = rp
+            scale = None
+            segs.append(res[1])
+        return ops.pointwise(segs, wt, scale, shift, a_code, slope).unsqueeze(3)
 
     def forward(self, x):
         bnw = getattr(self, self._bn_name, None)

@@ -566,16 +566,16 @@ def _pw_seg(spec, B, name):
     if idx is not None:
         idx = _idx32(idx, name + " index").reshape(B, -1)
         n = idx.shape[1]
-    seg = _lib.PwSeg(x.data_ptr(), idx.data_ptr() if idx is not None else None, x.shape[1], x.shape[2], 0)
+    seg = _lib.PwSeg(x.data_ptr(), idx.data_ptr() if idx is not None else None, x.shape[1], x.shape[2])
     return seg, (x, idx), n
 
 
-def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, res=None, point_major=False, out=None, out_c0=0):
+def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_major=False, out=None, out_c0=0):
     """One per-point (1x1) layer in one launch (include/gdm.h gdm_pointwise_hip), inference only:
-        y[b,:,i] = act(scale * (W . cat(segs)[b,:,i]) + shift (+ rscale * (Wr . xr[b,:,i]) + rshift))
-    segs: a list of one or two of  x f32[B,C,n(,1)]  or  (x f32[B,C,n_src(,1)], idx int[B,n(,1)])  -- the concat along channels is
-    never formed, an indexed segment is read through its index (nearest-neighbour interpolation folded into the load).
-    wt f32[K,Cout]: the layer's weight TRANSPOSED (K = total input channels).  res = (segment, rwt f32[Cr,Cout], rscale, rshift).
+        y[b,:,i] = act(scale * (W . cat(segs)[b,:,i]) + shift)
+    segs: a list of one to three of  x f32[B,C,n(,1)]  or  (x f32[B,C,n_src(,1)], idx int[B,n(,1)])  -- the concat along channels
+    is never formed, an indexed segment is read through its index (nearest-neighbour interpolation folded into the load).
+    wt f32[K,Cout]: the layer's weight TRANSPOSED (K = total input channels).
     Returns f32[B,Cout,n], or f32[B,n,Cout] when point_major; with `out` (f32[B,outC,n] / [B,n,outC]) channels
     [out_c0, out_c0+Cout) of it are written instead."""
     if not isinstance(segs, list):
@@ -599,17 +599,6 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, res=Non
         n = ni
     if ksum != K:
         raise ValueError("pointwise: weight has %d input rows, the segments %d channels" % (K, ksum))
-    rseg = rwt = rs = rb = None
-    if res is not None:
-        rspec, rwt, rs, rb = res
-        rseg_v, k, ni = _pw_seg(rspec, B, "residual segment")
-        keep.append(k)
-        if (ni if ni is not None else rseg_v.n_src) != n:
-            raise ValueError("pointwise: residual segment has another number of points")
-        rwt = _dev(rwt, torch.float32, "rwt")
-        if tuple(rwt.shape) != (rseg_v.C, Cout):
-            raise ValueError("pointwise: residual weight must be [%d,%d], got %s" % (rseg_v.C, Cout, tuple(rwt.shape)))
-        rseg = ctypes.pointer(rseg_v)
     if out is None:
         out = torch.empty((B, n, Cout) if point_major else (B, Cout, n), dtype=torch.float32, device=wt.device)
         outC = Cout
@@ -618,10 +607,8 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, res=Non
         if not out.is_contiguous() or out.dtype != torch.float32 or out.shape[0] != B or (out.shape[1] if point_major else out.shape[2]) != n:
             raise ValueError("pointwise: out must be a contiguous f32 [B,%s] tensor" % ("n,outC" if point_major else "outC,n"))
     check(_lib.lib().gdm_pointwise_hip(arr, len(segs), wt.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                       shift.data_ptr() if shift is not None else None, rseg, rwt.data_ptr() if rwt is not None else None,
-                                       rs.data_ptr() if rs is not None else None, rb.data_ptr() if rb is not None else None,
-                                       B, n, Cout, int(act), float(slope), out.data_ptr(), outC, int(out_c0), 1 if point_major else 0,
-                                       _stream()), "gdm_pointwise_hip")
+                                       shift.data_ptr() if shift is not None else None, B, n, Cout, int(act), float(slope),
+                                       out.data_ptr(), outC, int(out_c0), 1 if point_major else 0, _stream()), "gdm_pointwise_hip")
     return out
 
 

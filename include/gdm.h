@@ -450,19 +450,20 @@ int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, in
  * models/RandLA/pytorch_utils.py:34-99, the tail lrelu(mlp2(f) + shortcut(x)) of Dilated_res_block (RandLANet.py:685-688), the
  * fusion layers over cat(point, pooled pixel) features (ffb6d.py:224-231,259-265) and the decoder layers over
  * cat(skip, nearest_interpolation(deeper)) (ffb6d.py:246-250,268-272; the interpolation = `idx` of the second segment).
- *   out[b, out_c0 + c, i] = act( scale[c] * sum_k wt[k][c] * X[b,k,i] + shift[c]  (+ rscale[c] * sum_k rwt[k][c] * Xr[b,k,i] + rshift[c]) )
- * X = the channels of segs[0] followed by those of segs[1] (the concat, never formed).  A segment is f32[B,C,n_src] channel-major
- * (point_major 0) or f32[B*n_src,C] (point_major 1), read at column i (n_src == n) or at idx[b*n + i] (i32, any n_src).
- * wt f32[K,Cout] TRANSPOSED weight, K = sum of the segments' C; scale / shift / rscale / rshift f32[Cout] or NULL (1 / 0).
+ *   out[b, out_c0 + c, i] = act( scale[c] * sum_k wt[k][c] * X[b,k,i] + shift[c] )
+ * X = the channels of segs[0], segs[1], segs[2] in order (the concat, never formed; nseg in [1,3]).  A segment is f32[B,C,n_src]
+ * channel-major, read at column i (n_src == n) or at idx[b*n + i] (i32, any n_src).  A residual branch
+ * s1*(W1 . x1) + b1 + s2*(W2 . x2) + b2 is the two-segment layer with wt = [s1*W1^T ; s2*W2^T], shift = b1 + b2 (the caller folds).
+ * wt f32[K,Cout] TRANSPOSED weight, K = sum of the segments' C; scale / shift f32[Cout] or NULL (1 / 0).
  * act: 0 none, 1 ReLU, 2 leaky ReLU (slope).  out f32[B,out_C,n] (point_major 0) or f32[B*n,out_C] (1), 16-byte aligned;
- * channels [out_c0, out_c0 + Cout) of it are written.  fp32 FMAs, ascending-k summation. */
+ * channels [out_c0, out_c0 + Cout) of it are written.  fp32 FMAs; the K axis may be summed as up to four partial sums added in
+ * fixed order (deterministic; no atomics). */
 typedef struct {
     const float* x;
     const int32_t* idx;
-    int32_t C, n_src, point_major;
+    int32_t C, n_src;
 } gdm_pw_seg;
 int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
-                      const gdm_pw_seg* rseg, const float* rwt, const float* rscale, const float* rshift,
                       int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
 
 #ifdef __cplusplus

@@ -677,18 +677,21 @@ def test_affine_relu_maxpool_equals_modules(ops, B, C, H, W):
     assert (got - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B,n,cs,cout,n_src,res_c,pm", [
-    (16, 2048, (8,), 16, None, None, False),          # DilatedResBlock(8, 32).mlp1
-    (16, 2048, (32,), 64, None, 8, False),            # its tail: lrelu(bn(mlp2) + bn(shortcut))
-    (16, 8, (512, 512), 512, None, None, False),      # deepest r2p fuse over cat(p_emb0, r2p_emb): 8 points per crop
-    (2, 512, (64, 128), 64, 128, None, False),        # decoder over cat(skip, nearest_interpolation(deeper))
-    (3, 37, (5, 3), 7, 11, 6, False),                 # ragged everything
-    (4, 512, (64,), 64, None, None, True),            # point-major product for the 64-channel fusion kernel
-    (2, 130, (70,), 130, None, None, True),
+@pytest.mark.parametrize("B,n,cs,cout,n_src,pm", [
+    (16, 2048, (8,), 16, None, False),                # DilatedResBlock(8, 32).mlp1
+    (16, 2048, (32, 8), 64, None, False),             # its tail lrelu(bn(mlp2(f)) + bn(shortcut(x))) as one layer over [f ; x]
+    (16, 8, (512, 512), 512, None, False),            # deepest r2p fuse over cat(p_emb0, r2p_emb): 8 points per crop, K split in 4
+    (16, 8, (512,), 1024, None, False),               # deepest p2r pre layer: 128 points, 1024 channels out
+    (16, 32, (256, 256), 512, None, False),           # level-3 tail: K split in 2
+    (2, 512, (64, 128), 64, 128, False),              # decoder over cat(skip, nearest_interpolation(deeper))
+    (3, 37, (5, 3, 6), 7, 11, False),                 # ragged everything, three segments
+    (1, 50, (70,), 3, None, False),                   # ragged K with the split (few points)
+    (4, 512, (64,), 64, None, True),                  # point-major product for the 64-channel fusion kernel
+    (2, 130, (70,), 130, None, True),
 ])
-def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, res_c, pm):
-    """ops.pointwise (gdm_pointwise_hip) == cat -> 1x1 conv -> affine (folded BN) -> (+ residual branch) -> activation in fp64 torch,
-    to fp32 rounding of a K-term dot product (1e-5 relative to the output scale); indexed segment = nearest interpolation."""
+def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, pm):
+    """ops.pointwise (gdm_pointwise_hip) == cat -> 1x1 conv -> affine (folded BN) -> activation in fp64 torch, to fp32 rounding
+    of a K-term dot product (1e-5 relative to the output scale); an indexed segment = nearest interpolation of its source."""
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + n)
     xs, segs = [], []
     for j, c in enumerate(cs):
@@ -705,15 +708,8 @@ def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, res_c, pm):
     w = (torch.randn(cout, K, generator=g) / K ** 0.5).cuda()
     scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
     want = torch.einsum("ok,bkn->bon", w.double(), torch.cat(xs, 1).double()) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1)
-    res = None
-    if res_c is not None:
-        xr = torch.randn(B, res_c, n, generator=g).cuda()
-        wr = torch.randn(cout, res_c, generator=g).cuda()
-        rs, rb = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
-        want = want + torch.einsum("ok,bkn->bon", wr.double(), xr.double()) * rs.double().view(1, -1, 1) + rb.double().view(1, -1, 1)
-        res = (xr, wr.t().contiguous(), rs, rb)
     want = torch.where(want > 0, want, want * 0.2)
-    got = ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, res=res, point_major=pm)
+    got = ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, point_major=pm)
     if pm:
         assert got.shape == (B, n, cout)
         got = got.transpose(1, 2)
@@ -722,8 +718,32 @@ def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, res_c, pm):
     # channel-offset output: the layer writes channels [c0, c0 + cout) of a wider tensor and nothing else
     if not pm:
         wide = torch.full((B, cout + 9, n), 7.0, device="cuda")
-        ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, res=res, out=wide, out_c0=5)
+        ops.pointwise(segs, w.t().contiguous(), scale, shift, ops.ACT_LEAKY, 0.2, out=wide, out_c0=5)
         assert torch.equal(wide[:, 5:5 + cout], got) and bool((wide[:, :5] == 7).all()) and bool((wide[:, 5 + cout:] == 7).all())
+    # no scale / shift / activation: the plain product
+    plain = ops.pointwise(segs, w.t().contiguous(), point_major=pm)
+    want = torch.einsum("ok,bkn->bon", w.double(), torch.cat(xs, 1).double())
+    assert ((plain.transpose(1, 2) if pm else plain).double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_dilated_res_block_tail_as_one_layer_equals_modules():
+    """lrelu(bn(mlp2(f)) + bn(shortcut(x))) (RandLANet.py:685-688) through the folded two-segment layer == the torch modules (fp64)."""
+    from geometric_aware_dense_matching_amd import ops as o
+    from geometric_aware_dense_matching_amd.randla import DilatedResBlock
+    torch.manual_seed(5)
+    blk = DilatedResBlock(8, 32).cuda().eval()
+    for m in (blk.mlp2, blk.shortcut):
+        bn = m.bn.bn
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(); bn.bias.data.normal_()
+    f = torch.randn(3, 32, 200, 1, device="cuda")
+    x = torch.randn(3, 8, 200, 1, device="cuda")
+    with torch.no_grad():
+        got = blk.mlp2.forward_segs([f], res=(blk.shortcut, x), act=(o.ACT_LEAKY, 0.2))
+        blk64 = DilatedResBlock(8, 32).cuda().double().eval()
+        blk64.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+        want = torch.nn.functional.leaky_relu(torch.nn.Sequential.forward(blk64.mlp2, f.double())
+                                              + torch.nn.Sequential.forward(blk64.shortcut, x.double()), 0.2)
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
 def test_pointwise_rejects_bad_arguments(ops):
