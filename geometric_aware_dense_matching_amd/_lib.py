@@ -126,6 +126,16 @@ class PwSeg(ctypes.Structure):
     _fields_ = [("x", _vp), ("idx", _vp), ("C", ctypes.c_int32), ("n_src", ctypes.c_int32)]
 
 
+class CopyJob(ctypes.Structure):
+    """gdm_copy_job (include/gdm.h)."""
+    _fields_ = [("dst", _vp), ("src", _vp), ("sb", ctypes.c_int64), ("s1", ctypes.c_int64), ("s2", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("R1", ctypes.c_int32), ("R2", ctypes.c_int32), ("E", ctypes.c_int32)]
+
+
+SIGNATURES["gdm_stem_weight_bytes"] = (_sz, [])
+SIGNATURES["gdm_stem_pack_weight_hip"] = (_i, [_vp, _vp, _vp])
+SIGNATURES["gdm_stem_hip"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp])
+SIGNATURES["gdm_copy_jobs_hip"] = (_i, [ctypes.POINTER(CopyJob), _i, _vp])
 SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 
 _lib = None

@@ -527,3 +527,56 @@ extern "C" int gdm_seg_mask_hip(const float* seg, int B, int N, uint8_t* mask, i
     hipLaunchKernelGGL(seg_mask_kernel, dim3(gdm_cdiv(N, GB), B), dim3(GB), 0, STREAM(stream), seg, N, mask, count);
     return gdm_launch_status("seg_mask_kernel");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched strided copies: the strided xyz grids (linemod_pbr.py:517-527), the prefix sub-clouds (:538) and the pooling index
+// prefixes of a whole neighbour pyramid, each a dense [B, R1, R2, E] array of 4-byte words read from a strided view -- one launch
+// for the whole table instead of one `contiguous()` copy kernel per view.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct CopyTable {
+    gdm_copy_job j[GDM_COPY_MAX_JOBS];
+    long begin[GDM_COPY_MAX_JOBS + 1];    // first word (of the launch) of every job
+    int n;
+};
+
+__global__ __launch_bounds__(256) void copy_jobs_kernel(const CopyTable t)
+{
+    const long w = (long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= t.begin[t.n]) return;
+    int ji = 0;
+    while (ji + 1 < t.n && w >= t.begin[ji + 1]) ++ji;
+    const gdm_copy_job& j = t.j[ji];
+    long r = w - t.begin[ji];
+    const int e = (int)(r % j.E);
+    r /= j.E;
+    const int r2 = (int)(r % j.R2);
+    r /= j.R2;
+    const int r1 = (int)(r % j.R1);
+    const long b = r / j.R1;
+    static_cast<uint32_t*>(j.dst)[w - t.begin[ji]] =
+        static_cast<const uint32_t*>(j.src)[b * j.sb + (long)r1 * j.s1 + (long)r2 * j.s2 + e];
+}
+
+} // namespace
+
+extern "C" int gdm_copy_jobs_hip(const gdm_copy_job* jobs, int njobs, void* stream)
+{
+    GDM_CHECK_ARG(jobs && njobs >= 1 && njobs <= GDM_COPY_MAX_JOBS, "gdm_copy_jobs_hip: njobs=%d out of range", njobs);
+    CopyTable t;
+    t.n = njobs;
+    long total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const gdm_copy_job& j = jobs[i];
+        GDM_CHECK_ARG(j.dst && j.src && j.B >= 1 && j.R1 >= 1 && j.R2 >= 1 && j.E >= 1, "gdm_copy_jobs_hip: job %d is empty", i);
+        t.j[i] = j;
+        t.begin[i] = total;
+        total += (long)j.B * j.R1 * j.R2 * j.E;
+    }
+    t.begin[njobs] = total;
+    GDM_CHECK_ARG(total <= 0x7fffffffL * 256, "gdm_copy_jobs_hip: too many words");
+    hipLaunchKernelGGL(copy_jobs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t);
+    return gdm_launch_status("copy_jobs_kernel");
+}

@@ -177,12 +177,25 @@ class FFB6DEmb(nn.Module):
             pre = self.cnn_pre_stages                                         # conv1, bn1, relu, maxpool
             s0, b0 = folded_bn(pre[1])
             mp = pre[3]
-            y0 = pre[0](inputs["rgb"])
-            if (isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (3, (3, 3)) and mp.stride in (2, (2, 2)) and mp.padding in (1, (1, 1))
-                    and mp.dilation in (1, (1, 1)) and not mp.ceil_mode and isinstance(pre[2], nn.ReLU) and y0.shape[0] * y0.shape[1] <= 65535):
-                rgb_emb = ops.affine_relu_maxpool(y0, s0, b0)          # BN + ReLU + max-pool: one pass over the stem's map
+            conv = pre[0]
+            plain_pool = (isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (3, (3, 3)) and mp.stride in (2, (2, 2)) and mp.padding in (1, (1, 1))
+                          and mp.dilation in (1, (1, 1)) and not mp.ceil_mode and isinstance(pre[2], nn.ReLU))
+            if (settings.USE_OWN_STEM and plain_pool and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.bias is None
+                    and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and tuple(conv.dilation) == (1, 1)
+                    and inputs["rgb"].shape[0] <= 65535):
+                # the whole stem in one own launch (split-bf16 MFMA implicit GEMM, pooled in LDS): no library kernel is left in the step
+                key = (conv.weight._version, conv.weight.data_ptr())
+                cache = conv.__dict__.get("_gdm_stem_pk")
+                if cache is None or cache[0] != key:
+                    cache = (key, ops.stem_pack_weight(conv.weight))
+                    conv.__dict__["_gdm_stem_pk"] = cache
+                rgb_emb = ops.stem(inputs["rgb"], cache[1], s0, b0)
             else:
-                rgb_emb = mp(ops.affine_act(y0, s0, b0, ops.ACT_RELU))
+                y0 = conv(inputs["rgb"])
+                if plain_pool and y0.shape[0] * y0.shape[1] <= 65535:
+                    rgb_emb = ops.affine_relu_maxpool(y0, s0, b0)          # BN + ReLU + max-pool: one pass over the stem's map
+                else:
+                    rgb_emb = mp(ops.affine_act(y0, s0, b0, ops.ACT_RELU))
         else:
             pre = self.cnn_pre_stages
             rgb_emb = pre[3](bn_act(pre[1], pre[0](inputs["rgb"]), pre[2]))

@@ -158,6 +158,24 @@ def knn_jobs(jobs, B, keep_workspace=None):
     return outs
 
 
+def copy_views(views):
+    """Dense copies of a list of strided views in ONE launch (include/gdm.h gdm_copy_jobs_hip): every view is a 3-D or 4-D tensor
+    of 4-byte elements whose last dimension is contiguous.  Returns the dense tensors (same shapes)."""
+    n = len(views)
+    arr = (_lib.CopyJob * n)()
+    outs = []
+    for i, v in enumerate(views):
+        if not v.is_cuda or v.element_size() != 4 or v.dim() not in (3, 4) or v.stride(-1) != 1:
+            raise ValueError("copy_views: view %d must be a 3-D / 4-D CUDA tensor of 4-byte elements with a contiguous last dimension" % i)
+        out = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        v4 = v if v.dim() == 4 else v.unsqueeze(1)
+        arr[i] = _lib.CopyJob(out.data_ptr(), v.data_ptr(), v4.stride(0), v4.stride(1), v4.stride(2),
+                              v4.shape[0], v4.shape[1], v4.shape[2], v4.shape[3])
+        outs.append(out)
+    check(_lib.lib().gdm_copy_jobs_hip(arr, n, _stream()), "gdm_copy_jobs_hip")
+    return outs
+
+
 def _knn_launch(arr, n, B, device):
     """gdm_knn_jobs_ws_hip with a workspace from torch's caching allocator (graph-capture safe): the K > 1 jobs' support sets are
     re-laid out once per launch as hashed float4 tiles."""
@@ -935,6 +953,36 @@ def upconv_final_points(x_pm, hw, choose, wpk, scale, shift, act, slope, wf_pk, 
 
 
 _final_wt_cache = {}
+
+
+def stem_pack_weight(weight):
+    """w f32[64,3,7,7] -> fragment-ordered split-bf16 weights of the stem kernel (u8 tensor); cache it per weight version."""
+    w = _dev(weight.detach(), torch.float32, "weight")
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise ValueError("stem_pack_weight: the stem kernel is built for a [64,3,7,7] filter, got %s" % (tuple(w.shape),))
+    L = _lib.lib()
+    wpk = torch.empty(L.gdm_stem_weight_bytes(), dtype=torch.uint8, device=w.device)
+    check(L.gdm_stem_pack_weight_hip(w.data_ptr(), wpk.data_ptr(), _stream()), "gdm_stem_pack_weight_hip")
+    return wpk
+
+
+def stem(x, wpk, scale, shift, packed=True):
+    """maxpool3x3/2(relu(scale * conv7x7/2(x) + shift)) in one launch (include/gdm.h gdm_stem_hip).  x f32[B,3,H,W] ->
+    f32[B,64,PH,PW]; with `packed` the result also carries (`_gdm_packed`) the split-bf16 operand of the next 3x3 convolution."""
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    if C != 3:
+        raise ValueError("stem: 3 input channels, got %d" % C)
+    PH, PW = ((H - 1) // 2) // 2 + 1, ((W - 1) // 2) // 2 + 1
+    out = torch.empty((B, 64, PH, PW), dtype=torch.float32, device=x.device)
+    opk = None
+    if packed and (B * PH * PW) % 256 == 0 and PW % 16 == 0:
+        opk = PackedAct(_packed_buffer(B, 64, PH, PW, x.device), (B, 64, PH, PW))
+    check(_lib.lib().gdm_stem_hip(x.data_ptr(), wpk.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, H, W, out.data_ptr(),
+                                  opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_stem_hip")
+    if opk is not None:
+        out._gdm_packed = opk
+    return out
 
 
 def affine_relu_maxpool(x, scale, shift):

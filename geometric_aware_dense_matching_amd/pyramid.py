@@ -56,13 +56,17 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
     if N % 256 != 0 or N < 1024:
         raise ValueError("N=%d: four /4 levels must leave >= 16 points (N >= 1024, N %% 256 == 0)" % N)
     cld = cld.contiguous()
-    grids = {1: dpt_xyz.reshape(B, S * S, 3)}
-    for sc in (2, 4, 8):                                   # linemod_pbr.py:517-527 strided xyz maps
-        grids[sc] = dpt_xyz[:, ::sc, ::sc, :].reshape(B, -1, 3).contiguous()
-
-    levels = [cld]
+    dpt_xyz = dpt_xyz.contiguous()
+    n_lv = [N]
     for i in range(4):
-        levels.append(cld[:, : levels[-1].shape[1] // PCLD_SUB_SR[i]])      # prefix views, batch stride kept
+        n_lv.append(n_lv[-1] // PCLD_SUB_SR[i])
+    # the strided xyz maps (linemod_pbr.py:517-527) and the prefix sub-clouds (:538), dense, in ONE copy launch.  (The searches
+    # could read the prefix views in place -- batch stride kept -- but every later consumer wants them dense.)
+    dense = ops.copy_views([dpt_xyz[:, ::sc, ::sc, :] for sc in (2, 4, 8)] + [cld[:, :n_lv[i]] for i in (1, 2, 3, 4)])
+    grids = {1: dpt_xyz.reshape(B, S * S, 3)}
+    for sc, g in zip((2, 4, 8), dense[:3]):
+        grids[sc] = g.reshape(B, -1, 3)
+    levels = [cld] + dense[3:]
 
     jobs, names = [], []
     for i in range(4):
@@ -74,15 +78,14 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
         jobs += [(px, pts, K_NEI, S // RGB_UP_SR[i]), (pts, px, 1)]
         names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
     if _keep is not None:
-        _keep += [grids[sc] for sc in (2, 4, 8)]
+        _keep += dense
     outs = ops.knn_jobs(jobs, B, keep_workspace=_keep)
 
     pyr = dict(zip(names, outs))
+    subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])     # pooling indices: prefix rows, dense
     for i in range(4):
-        # prefix views are batch-strided; every consumer (two LFA stage launches per level, the pooling gather) wants them dense,
-        # so they are made contiguous once here instead of once per use
-        pyr["cld_xyz%d" % i] = levels[i].contiguous()
-        pyr["cld_sub_idx%d" % i] = pyr["cld_nei_idx%d" % i][:, : levels[i + 1].shape[1]].contiguous()
+        pyr["cld_xyz%d" % i] = levels[i]
+        pyr["cld_sub_idx%d" % i] = subs[i]
     return pyr
 
 

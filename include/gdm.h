@@ -466,6 +466,31 @@ typedef struct {
 int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
                       int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * The ResNet stem in one launch (inference): conv 7x7 / stride 2 / pad 3 (3 -> 64, no bias) + scale / shift (folded BatchNorm) +
+ * ReLU + max-pool 3x3 / stride 2 / pad 1 (/root/reference/models/cnn/extractors.py:112-116,181-185: conv1, bn1, relu, maxpool).
+ * x f32[B,3,H,W] -> out f32[B,64,PH,PW] (PH = ((H-1)/2)/2 + 1, PW likewise) and / or out_packed = the split-bf16 operand planes of
+ * the next 3x3 convolution (gdm_conv3x3_act_bytes(B, 64, PH, PW) bytes, zero border already in place); either may be NULL.
+ * wpk: gdm_stem_pack_weight_hip of w f32[64,3,7,7] (gdm_stem_weight_bytes() bytes).  Split-bf16 products, fp32 accumulate. */
+size_t gdm_stem_weight_bytes(void);
+int gdm_stem_pack_weight_hip(const float* w, void* wpk, void* stream);
+int gdm_stem_hip(const float* x, const void* wpk, const float* scale, const float* shift, int B, int H, int W, float* out,
+                 void* out_packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Batched strided copies of 4-byte words (f32 / i32), one launch for a table of views: job i fills the dense array
+ * dst[B][R1][R2][E] from src[b*sb + r1*s1 + r2*s2 + e] (strides in words).  The neighbour pyramid uses it for the strided xyz
+ * grids (datasets/lm/linemod_pbr.py:517-527: R1 x R2 = rows x columns at stride sr), the prefix sub-clouds (:538) and the pooling
+ * index prefixes, which the reference makes with numpy slicing + copies in the DataLoader worker. */
+typedef struct gdm_copy_job {
+    void* dst;
+    const void* src;
+    int64_t sb, s1, s2;
+    int32_t B, R1, R2, E;
+} gdm_copy_job;
+#define GDM_COPY_MAX_JOBS 16
+int gdm_copy_jobs_hip(const gdm_copy_job* jobs /* host array */, int njobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

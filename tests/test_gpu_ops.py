@@ -754,3 +754,30 @@ def test_pointwise_rejects_bad_arguments(ops):
         ops.pointwise([x, torch.randn(2, 8, 32, device="cuda")], torch.randn(16, 4, device="cuda"))   # segments disagree on n
     with pytest.raises(RuntimeError):
         ops.pointwise([x.cpu()], torch.randn(8, 4))                              # no CPU path
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 100, 70), (3, 64, 128), (1, 7, 9)])
+def test_stem_kernel_vs_torch_fp64(ops, B, H, W):
+    """gdm_stem_hip == maxpool3x3/2/p1(relu(bn(conv7x7/2/p3(x)))) (extractors.py:112-116,181-185) in fp64 torch: split-bf16 products
+    (|err| <= 3 * 2^-18 per product over 147 terms): 2e-5 relative to the output scale.  The packed operand it also writes is
+    byte-identical to what the pack kernel makes of its fp32 output."""
+    from geometric_aware_dense_matching_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + W)
+    x = torch.randn(B, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda()
+    scale, shift = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    got = ops.stem(x, ops.stem_pack_weight(w), scale, shift)
+    y = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=3)
+    y = torch.relu(y * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    want = torch.nn.functional.max_pool2d(y, 3, 2, 1)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    pk = getattr(got, "_gdm_packed", None)
+    PH, PW = got.shape[2], got.shape[3]
+    if (B * PH * PW) % 256 == 0 and PW % 16 == 0:
+        assert pk is not None and pk.shape == tuple(got.shape)
+        mine = pk.buf.clone()                                     # the pool may hand the same buffer to the pack launch below
+        ref = ops.conv3x3_pack_act(got.clone())
+        assert torch.equal(ref.buf, mine)
+    else:
+        assert pk is None
