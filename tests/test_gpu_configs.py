@@ -9,6 +9,8 @@ and tools/ddp_rehearsal.py):
             batched Kabsch pose and ADD / ADI -- against the reference's lines restated in oracle/ (evaluator.py:78-100 matching +
             best_fit_transform + pysixd add / adi, pinned by matching.npz / pose.npz) applied to the same descriptors
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -132,3 +134,99 @@ def test_config5_lmo_eval_pipeline_pose_and_add_vs_reference_lines():
         adi_w = pose_ref.adi(Te[:, :3], Te[:, 3], gt[:, :3].astype(np.float64), gt[:, 3].astype(np.float64), sub.astype(np.float64))
         assert abs(add_g - add_w) < 1e-6 and abs(adi_g - adi_w) < 1e-6
         assert add_w < 0.1 * ds["diameters"][cid] / 1000.0             # the ADD(-S) < 0.1 d criterion holds for a 2 mm-noise pose
+
+
+def _ycbv_rank_worker(rank, world, port, out):
+    """One DDP + SyncBatchNorm training step of the YCB-V configuration at its workload size, two ranks over gloo on this GPU."""
+    import torch.distributed as dist
+    from geometric_aware_dense_matching_amd import parallel, train_lm, train_ycb
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world))
+    parallel.init_distributed("gloo")
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        args = train_ycb.build_parser().parse_args("-state=train -cls_id=21 --n-points 4096 --n-mesh 4096 --synthetic-items 8".split())
+        torch.manual_seed(0)
+        model = train_lm.build_model(args, 21).to(dev)
+        ddp = parallel.wrap_for_training(model, local_rank=0)
+        opt = torch.optim.Adam(ddp.parameters(), lr=1e-4)
+        ds = train_lm.SyntheticCrops(4, 4096, 4096, seed=3)
+        batch = torch.utils.data.default_collate([ds[rank * 2 + i] for i in range(2)])      # global batch 4, two crops per rank
+        ddp.train()
+        res, _ = train_lm.model_fn_dec(ddp, batch, dev)
+        res["loss"].backward()
+        grads_finite = all(torch.isfinite(p.grad).all().item() for p in ddp.parameters() if p.grad is not None)
+        opt.step()
+        torch.cuda.synchronize()
+        chk = torch.stack([p.detach().double().sum() for p in ddp.parameters()]).cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok = bool(torch.isfinite(res["loss"]).item()) and grads_finite and torch.equal(lo, hi) and bool(torch.isfinite(chk).all())
+        if rank == 0:
+            out.put("ok" if ok else "FAIL loss=%r finite_grads=%r in_sync=%r" % (float(res["loss"]), grads_finite, torch.equal(lo, hi)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_ycbv_training_step_at_workload_size():
+    """BASELINE config 3 at ITS size: YCB-V (config/ycbv_cfg.py:100-136: 21-object table, neighbor_dis_th 0.06), object 21
+    (061_foam_brick, one of the dataset's symmetric objects), N = M = 4096, batch 4, through train_ycb's own model builder.
+      (1) one training step (forward, fused matching + circle loss, backward, Adam): finite loss / gradients, parameters move;
+      (2) the matching loss of items 0-1 on the step's OWN descriptors vs oracle/loss_ref.py (geoMatch.py:102-157 restated on the
+          CPU, radius = 0.06 * diameter(21)): value 2e-5 relative, both gradients 2e-3 relative;
+      (3) the same step as two DDP + SyncBatchNorm ranks (gloo, global batch 4): finite, and parameters bit-equal across ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from geometric_aware_dense_matching_amd import config, train_lm, train_ycb
+    from oracle import loss_ref
+    args = train_ycb.build_parser().parse_args("-state=train -cls_id=21 --n-points 4096 --n-mesh 4096 --synthetic-items 8".split())
+    ds = config.dataset_config(args.dataset_name)
+    assert args.dataset_name == "ycbv" and len(ds["objs"]) == 21 and ds["neighbor_dis_th"] == 0.06 and ds["objs"][21] in ds["sym_objs"]
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = train_lm.build_model(args, 21).to(dev).train()
+    assert abs(model.positive_r - 0.06 * config.YCBV_DIAMETERS[21] / 1000.0) < 1e-9
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    data = train_lm.SyntheticCrops(4, 4096, 4096, seed=3)
+    batch = torch.utils.data.default_collate([data[i] for i in range(4)])
+    before = [p.detach().clone() for p in model.parameters()]
+    res, cu = train_lm.model_fn_dec(model, batch, dev)
+    assert res["rgbd"].shape == (4, 128, 4096) and res["mesh"].shape == (1, 128, 4096)
+    res["loss"].backward()
+    assert torch.isfinite(res["loss"]) and torch.isfinite(res["match_loss"]) and torch.isfinite(res["seg_loss"])
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 300 and all(torch.isfinite(g).all() for g in grads)
+    opt.step()
+    moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, model.parameters()))
+    assert moved > 300
+    # (2) matching loss of a sub-batch on the step's own descriptors vs the oracle
+    sub = {k: cu[k][:2] for k in ("labels", "match_idx", "visible_flag", "RT")}
+    rg = res["rgbd"][:2].detach().clone().requires_grad_(True)
+    mg = res["mesh"].detach().clone().requires_grad_(True)
+    got = model.pointwise_feature_matching(rg, mg, sub)
+    got.backward()
+    rc = res["rgbd"][:2].detach().cpu().clone().requires_grad_(True)
+    mc = res["mesh"].detach().cpu().clone().requires_grad_(True)
+    sys_idx = getattr(model.model_emb, "sys_idx", None)
+    want = loss_ref.pointwise_feature_matching(rc, mc, sub["labels"].cpu().long(), sub["match_idx"].cpu().long(), sub["visible_flag"].cpu(),
+                                               model.model_emb.xyz.cpu(), model.positive_r,
+                                               sys_idx=sys_idx.cpu() if sys_idx is not None else None)
+    want.backward()
+    assert abs(got.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
+    for a, b in ((rg.grad.cpu(), rc.grad), (mg.grad.cpu(), mc.grad)):
+        assert (a - b).norm().item() < 2e-3 * (b.norm().item() + 1e-20)
+    del model, opt, res, cu
+    torch.cuda.empty_cache()
+    # (3) two ranks
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_ycbv_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert out.get() == "ok"
