@@ -189,6 +189,15 @@ class PSPModule(nn.Module):
             self.__dict__["_gdm_split"] = cache
         return cache[1], cache[2]
 
+    def _split_weights_t(self, ms):
+        """The folded prior matrices transposed ([Cin, Cout], the per-point kernel's weight layout), cached beside them."""
+        cache = self.__dict__.get("_gdm_split_t")
+        if cache is None or cache[0] is not ms:
+            with torch.no_grad():
+                cache = (ms, [m.t().contiguous() for m in ms])
+            self.__dict__["_gdm_split_t"] = cache
+        return cache[1]
+
     def forward(self, feats):
         h, w = feats.size(2), feats.size(3)
         if fused_eval(feats, self) and len(self.stages) == 4 and feats.shape[0] * self.bottleneck.out_channels <= 65535:
@@ -204,10 +213,14 @@ class PSPModule(nn.Module):
             sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
             pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w) else None
             ys = []
+            mts = self._split_weights_t(ms) if settings.USE_POINTWISE else None
             for k, (st, m) in enumerate(zip(self.stages, ms)):
                 p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
                 s_ = p.shape[2]
-                ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
+                if mts is not None:
+                    ys.append(ops.pointwise([p.reshape(B, Cin, s_ * s_)], mts[k]).view(B, -1, s_, s_))   # M_k . pool_k(f): own kernel
+                else:
+                    ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
             return ops.psp_combine(g, ys, self.bottleneck.bias)
         sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
         if (settings.USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
@@ -303,6 +316,8 @@ class FinalStage(nn.Sequential):
         conv = self[0]
         if fused_eval(x, self) and conv.in_channels == 64 and conv.out_channels == 64 and x.shape[0] <= 65535:
             return ops.conv1x1_logsoftmax(x, conv.weight, conv.bias)
+        if self.training and ops.conv1x1_train_supported(conv, x):
+            return self[1](ops.conv1x1_train(conv, x))
         return nn.Sequential.forward(self, x)
 
 

@@ -179,11 +179,17 @@ class _FusedConvMixin:
             act = getattr(self, "activation", None)
             code = train_act_code(act)
             if code is not None:
-                y = self.conv(x)
+                y = ops.conv1x1_train(self.conv, x) if ops.conv1x1_train_supported(self.conv, x) else self.conv(x)
                 if ops.bn_train_supported(y, bnw.bn):
                     return ops.batch_norm_act_train(y, bnw.bn, code[0], code[1])
                 y = bnw(y)
                 return act(y) if act is not None else y
+        if self.training and ops.conv1x1_train_supported(self.conv, x):
+            y = ops.conv1x1_train(self.conv, x)
+            for name, mod in self.named_children():
+                if name != "conv":
+                    y = mod(y)
+            return y
         return nn.Sequential.forward(self, x)
 
 

@@ -803,6 +803,52 @@ def wx(w2d, x3):
     return torch.bmm(w2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
 
 
+class _Conv1x1Train(torch.autograd.Function):
+    """y[b] = W . x[b] (+ bias) for a 1x1 convolution, with all three products as batched GEMMs on the NCHW tensors as they lie:
+    forward W . x, input gradient W^T . go, weight gradient sum_b go[b] . x[b]^T.  torch's convolution backward sends a 1x1
+    convolution to MIOpen's implicit-GEMM wgrad / bwd-data kernels, which want NHWC and pay a transposing copy of every operand
+    (181 `batched_transpose` launches, 2.7 ms of a 56 ms training step) around fp32 kernels slower than the GEMM library's."""
+
+    @staticmethod
+    def forward(ctx, x, w2, bias):
+        B, Cin = x.shape[0], x.shape[1]
+        x3 = x.reshape(B, Cin, -1)
+        ctx.save_for_backward(x3, w2)
+        ctx.xshape = x.shape
+        ctx.has_bias = bias is not None
+        y = torch.empty((B, w2.shape[0]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)   # returned as it is (not a view: the
+        y3 = y.view(B, w2.shape[0], -1)                                                            # modules' in-place activations follow)
+        torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x3, out=y3)
+        if bias is not None:
+            y3 += bias.view(1, -1, 1)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x3, w2 = ctx.saved_tensors
+        B = x3.shape[0]
+        go3 = go.reshape(B, w2.shape[0], -1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go3).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(go3, x3.transpose(1, 2)).sum(0)            # [B, Cout, Cin] partials: <= 25 MB for every layer but one
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = go3.sum((0, 2))
+        return gx, gw, gb
+
+
+def conv1x1_train_supported(conv, x):
+    return (settings.USE_GEMM_CONV1X1_TRAIN and x.is_cuda and x.dtype == torch.float32 and all(k == 1 for k in conv.kernel_size)
+            and all(st == 1 for st in conv.stride) and all(p == 0 for p in conv.padding) and conv.groups == 1 and x.dim() in (3, 4))
+
+
+def conv1x1_train(conv, x):
+    """Differentiable 1x1 convolution of an nn.Conv1d / nn.Conv2d module as batched GEMMs (see _Conv1x1Train)."""
+    w = conv.weight
+    return _Conv1x1Train.apply(x.contiguous(), w.reshape(w.shape[0], w.shape[1]), conv.bias)
+
+
 def upconv_train_supported(B, cout):
     return B * 9 * cout <= 65535
 

@@ -28,7 +28,10 @@ class AttPooling(nn.Module):
         self.mlp = rl_conv2d(d_in, d_out, bn=True)
 
     def forward(self, feature_set):                       # [B,C,n,K]
-        att_activation = self.fc(feature_set)
+        if self.training and ops.conv1x1_train_supported(self.fc, feature_set):
+            att_activation = ops.conv1x1_train(self.fc, feature_set)
+        else:
+            att_activation = self.fc(feature_set)
         f_agg = ops.att_pool(att_activation, feature_set)  # [B,C,n]
         return self.mlp(f_agg.unsqueeze(3))
 

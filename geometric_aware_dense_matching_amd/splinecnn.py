@@ -101,8 +101,18 @@ class SplineConv(nn.Module):
             # [M, 125*out] table, which is then never written), on the same split-bf16 MFMA kernel with gathered rows
             wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin),
                                         (self.weight,))
-            Y = ops.gemm_grouped(x.t().contiguous().unsqueeze(0), wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout)
-            root = self.lin(x)
+            xt = x.t().contiguous().unsqueeze(0)                     # [1, cin, M] channel-major: the GEMM's and the root layer's operand
+            Y = ops.gemm_grouped(xt, wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout)
+            if settings.USE_POINTWISE and self.lin.bias is None:
+                w = self.lin.weight
+                key = (w._version, w.data_ptr())
+                cache = self.__dict__.get("_gdm_root_t")
+                if cache is None or cache[0] != key:
+                    cache = (key, w.detach().t().contiguous())
+                    self.__dict__["_gdm_root_t"] = cache
+                root = ops.pointwise([xt], cache[1], point_major=True).view(M, self.cout)      # x @ W_root^T on the own kernel
+            else:
+                root = self.lin(x)
             out = torch.empty((M, self.cout), dtype=torch.float32, device=x.device)
             check(_lib.lib().gdm_spline_pairs_aggregate_hip(Y.data_ptr(), rowptr.data_ptr(), pairs["pos"].data_ptr(), pairs["basis"].data_ptr(),
                                                             root.data_ptr(), self.bias.data_ptr(), M, self.cout, int(relu), out.data_ptr(),

@@ -412,3 +412,27 @@ def test_training_step_through_fused_paths_equals_module_paths():
     # sums), the split-bf16 / fp64-sum paths within a bound that only an O(1) error would break
     assert dist(g1) < max(3e-2, 10.0 * noise), (dist(g1), noise)
     assert dist(g2) < 0.35, dist(g2)
+
+
+@pytest.mark.parametrize("shape,cout,bias", [((3, 16, 50), 24, True), ((2, 32, 40, 16), 32, False), ((2, 64, 24, 24), 64, True)])
+def test_conv1x1_train_as_batched_gemms_equals_torch_convolution(shape, cout, bias):
+    """ops.conv1x1_train (forward W.x, input gradient W^T.go, weight gradient sum_b go.x^T as batched GEMMs) == the nn.Conv1d / nn.Conv2d
+    module under autograd (fp64), followed by an in-place activation as the layer modules apply one."""
+    from geometric_aware_dense_matching_amd import ops
+    torch.manual_seed(cout)
+    cls = torch.nn.Conv1d if len(shape) == 3 else torch.nn.Conv2d
+    conv = cls(shape[1], cout, 1, bias=bias).cuda()
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    w = torch.randn(shape[0], cout, *shape[2:], device="cuda")
+    assert ops.conv1x1_train_supported(conv, x)
+    y = torch.nn.functional.leaky_relu_(ops.conv1x1_train(conv, x), 0.2)
+    (y * w).sum().backward()
+    got = [y.detach().double(), x.grad.double(), conv.weight.grad.double()] + ([conv.bias.grad.double()] if bias else [])
+    c64 = cls(shape[1], cout, 1, bias=bias).cuda().double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.leaky_relu(c64(x64), 0.2)
+    (y64 * w.double()).sum().backward()
+    want = [y64.detach(), x64.grad, c64.weight.grad] + ([c64.bias.grad] if bias else [])
+    for a, b in zip(got, want):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
