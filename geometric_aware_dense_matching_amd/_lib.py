@@ -135,6 +135,11 @@ class CopyJob(ctypes.Structure):
 SIGNATURES["gdm_stem_weight_bytes"] = (_sz, [])
 SIGNATURES["gdm_stem_pack_weight_hip"] = (_i, [_vp, _vp, _vp])
 SIGNATURES["gdm_stem_hip"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp])
+SIGNATURES["gdm_wgrad_x_bytes"] = (_sz, [_i, _i, _i, _i])
+SIGNATURES["gdm_wgrad_go_bytes"] = (_sz, [_i, _i, _i, _i])
+SIGNATURES["gdm_wgrad_pack_x_hip"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp])
+SIGNATURES["gdm_wgrad_pack_go_hip"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp])
+SIGNATURES["gdm_conv1x1_packed_wb_hip"] = (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_copy_jobs_hip"] = (_i, [ctypes.POINTER(CopyJob), _i, _vp])
 SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 

@@ -352,7 +352,10 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                                                                  const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
                                                                  float* __restrict__ out, const int32_t* __restrict__ rowidx = nullptr,
                                                                  const int32_t* __restrict__ tile_co0 = nullptr,
-                                                                 unsigned char* __restrict__ outpk = nullptr, int stride = 1)
+                                                                 unsigned char* __restrict__ outpk = nullptr, int stride = 1,
+                                                                 // per-image weights (the weight-gradient GEMM: image b of a workgroup's 256 pixels --
+                                                                 // H*W % 256 == 0 -- reads its rows at wpk + b * wbstride); 0 = shared weights
+                                                                 long wbstride = 0)
 {
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
@@ -399,8 +402,9 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
     constexpr int HS = MF_STAGE / 2;
     u32x4 stage[HS];
+    const unsigned char* wpk_b = wpk + (wbstride ? ((long)blockIdx.x * CV_PIX / hw) * wbstride : 0);
     auto stage_load = [&](int it, int half) {
-        const unsigned char* src = wpk + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
+        const unsigned char* src = wpk_b + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
             const int g = (half * HS + i) * MF_THREADS + tid;
@@ -729,6 +733,33 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
                                       int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream)
 {
     return conv1x1_launch(xpk, wpk, scale, shift, B, Cin, Cout, H, W, 1, act, pixel_major, out, stream);
+}
+
+// the same GEMM with one weight set PER IMAGE (include/gdm.h: the split-K parts of the weight-gradient GEMM): H*W % 256 == 0
+extern "C" int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long w_bstride, int B, int Cin, int Cout, int H, int W, float* out,
+                                         void* stream)
+{
+#if GDM_CONV_SHAPE == 16
+    GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_wb_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 1, "gdm_conv1x1_packed_wb_hip: Cin=%d Cout=%d (Cin a multiple of 128)", Cin, Cout);
+    GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CV_PIX == 0, "gdm_conv1x1_packed_wb_hip: W=%d must be a multiple of 32 and H*W=%d of %d",
+                  W, H * W, CV_PIX);
+    GDM_CHECK_ARG(w_bstride >= 0 && w_bstride % 16 == 0, "gdm_conv1x1_packed_wb_hip: w_bstride=%ld", w_bstride);
+    const long ptot = (long)B * H * W;
+    dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)CONV_KERNEL<0, false, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CV_PANEL);
+        attr = true;
+    }
+    hipLaunchKernelGGL((CONV_KERNEL<0, false, 1, false>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, (hipStream_t)stream, (const unsigned char*)xpk,
+                       (const unsigned char*)wpk, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, B, Cin, Cout, H, W, out,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, 1, w_bstride);
+    return gdm_launch_status("conv1x1_bf16x3_kernel (per-image weights)");
+#else
+    gdm_set_error("gdm_conv1x1_packed_wb_hip: built without the 16x16x32 kernel");
+    return GDM_EINVAL;
+#endif
 }
 
 // H, W = OUTPUT size; xpk = the (H stride) x (W stride) input (the downsample branch of a strided residual block reads every other pixel)

@@ -1,0 +1,134 @@
+// Weight gradient of the trunk's 3x3 / stride 1 / pad 1 convolutions on the matrix cores (training), gfx950.
+//
+//   dW[co, ci, ky, kx] = sum_{b, y, x} go[b, co, y, x] * in[b, ci, y + ky - 1, x + kx - 1]
+// (backward of /root/reference/models/cnn/extractors.py:36-58 under /root/reference/train_lm.py:285 `loss.backward()`; torch sends it
+// to MIOpen's fp32 implicit-GEMM wgrad kernels: 1.02 ms for 512 -> 512 at 32 x 32, batch 24 = 113 TFLOP/s, after NHWC transposes).
+// It is a GEMM whose contraction runs over the PIXELS of all images: dW_tap = GO (Cout x P) . X_tap^T (P x Cin).  The two kernels here
+// re-lay the operands so that the split-bf16 MFMA GEMM of gdm_conv.hip (conv_mfma16_kernel, 1x1 form) computes it unchanged:
+//   * its "input channels" (K) are the pixels kappa = b*H*W + p, in chunks of 128;
+//   * its "pixels" (n) are (tap, ci): a 9 x Cin grid, so one launch covers the nine taps;
+//   * its "weights" are the rows of GO: row (chunk, co) = bf16 hi | lo of go[b, co, 128 consecutive pixels].
+// A tap shift cannot be a pointer offset here (the pixels sit INSIDE the 8-element operand granules), so the X operand is written
+// nine times, once per tap, with the shift applied while the fp32 values pass through LDS (zero outside the map = the padding).
+// K is split over a few launches (chunk ranges = pointer offsets); the partial [Cout, 9, Cin] products are added by the caller.
+#include "gdm_common.h"
+
+namespace {
+
+// x f32[B,Cin,H,W] -> packed "activations" of the GEMM: K chunk c (global: b * (HW/128) + cl), plane q < 16 = hi of K rows
+// [8q, 8q+8) of the chunk, plane 16 + q = lo; element (tap + 1, ci + 1) of the (9 + 2) x (Cin + 2) grid, 16 B.
+// One block: one chunk x 64 input channels.
+template <int W>
+__global__ __launch_bounds__(256) void wgrad_pack_x_kernel(const float* __restrict__ x, int Cin, int H, unsigned char* __restrict__ out)
+{
+    constexpr int R = 128 / W;                    // image rows per chunk
+    constexpr int TS = (R + 2) * W + 1;           // floats per channel in LDS (+1: lanes = channels read conflict-free)
+    __shared__ float t[64 * TS];
+    const int tid = threadIdx.x;
+    const int hw = H * W, cpi = hw / 128;
+    const int c = blockIdx.x, b = c / cpi, cl = c - b * cpi;
+    const int y0 = (cl * 128) / W;
+    const int ci0 = blockIdx.y * 64;
+    for (int e = tid; e < 64 * (R + 2) * W; e += 256) {
+        const int xx = e % W, r = (e / W) % (R + 2), ci = e / ((R + 2) * W);
+        const int y = y0 - 1 + r;
+        float v = 0.f;
+        if (y >= 0 && y < H && ci0 + ci < Cin) v = x[(((long)b * Cin + ci0 + ci) * H + y) * W + xx];
+        t[ci * TS + r * W + xx] = v;
+    }
+    __syncthreads();
+    const long plane = (long)11 * (Cin + 2);
+    for (int item = tid; item < 9 * 16 * 64; item += 256) {
+        const int ci = item & 63, q = (item >> 6) & 15, tap = item >> 10;
+        if (ci0 + ci >= Cin) continue;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int pg = 8 * q, rr = pg / W, x0 = pg - rr * W;
+        const float* row = t + ci * TS + (rr + ky) * W;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int xs = x0 + kx - 1 + j;
+            v[j] = (xs >= 0 && xs < W) ? row[xs] : 0.f;
+        }
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gdm_split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+        unsigned char* o = out + ((((long)c * 32 + q) * plane) + (long)(tap + 1) * (Cin + 2) + ci0 + ci + 1) * 16;
+        *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + 16 * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+// go f32[B,Cout,H,W] -> packed "weights" of the GEMM: row (chunk * CoutP + co) = 512 B: bf16 hi of go[b, co, 128 cl .. + 128] | lo;
+// rows co >= Cout are zero.  Thread = (row, 8-pixel group).
+__global__ __launch_bounds__(256) void wgrad_pack_go_kernel(const float* __restrict__ go, int Cout, int CoutP, int hw, long rows,
+                                                            unsigned char* __restrict__ out)
+{
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= rows * 16) return;
+    const int g = (int)(item & 15);
+    const long row = item >> 4;
+    const int co = (int)(row % CoutP);
+    const long c = row / CoutP;
+    const int cpi = hw / 128;
+    const long b = c / cpi;
+    const int cl = (int)(c - b * cpi);
+    float v[8];
+    if (co < Cout) {
+        const float4* src = reinterpret_cast<const float4*>(go + (b * Cout + co) * hw + cl * 128 + 8 * g);
+        const float4 a = src[0], d = src[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gdm_split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+    unsigned char* r = out + row * 512;
+    *reinterpret_cast<uint4*>(r + g * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(r + 256 + g * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+bool shape_ok(int B, int C, int H, int W)
+{
+    return B >= 1 && C >= 1 && H >= 1 && (W == 32 || W == 64) && (H * W) % 128 == 0;
+}
+
+} // namespace
+
+extern "C" size_t gdm_wgrad_x_bytes(int B, int Cin, int H, int W)
+{
+    if (!shape_ok(B, Cin, H, W) || Cin % 32 != 0) return 0;
+    return (size_t)B * (H * W / 128) * 32 * 11 * (Cin + 2) * 16;
+}
+
+extern "C" size_t gdm_wgrad_go_bytes(int B, int Cout, int H, int W)
+{
+    if (!shape_ok(B, Cout, H, W)) return 0;
+    return (size_t)B * (H * W / 128) * ((Cout + 127) & ~127) * 512;
+}
+
+extern "C" int gdm_wgrad_pack_x_hip(const float* x, int B, int Cin, int H, int W, void* out, void* stream)
+{
+    GDM_CHECK_ARG(x && out, "gdm_wgrad_pack_x_hip: NULL pointer");
+    GDM_CHECK_ARG(shape_ok(B, Cin, H, W) && Cin % 32 == 0, "gdm_wgrad_pack_x_hip: unsupported shape B=%d Cin=%d H=%d W=%d (W in {32, 64}, H*W %% 128 == 0, "
+                  "Cin %% 16 == 0)", B, Cin, H, W);
+    GDM_CHECK_ARG(((uintptr_t)out & 15) == 0, "gdm_wgrad_pack_x_hip: out must be 16-byte aligned");
+    dim3 grid(B * (H * W / 128), gdm_cdiv(Cin, 64));
+    if (W == 32) hipLaunchKernelGGL(wgrad_pack_x_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, H, (unsigned char*)out);
+    else hipLaunchKernelGGL(wgrad_pack_x_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, H, (unsigned char*)out);
+    return gdm_launch_status("wgrad_pack_x_kernel");
+}
+
+extern "C" int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, int W, void* out, void* stream)
+{
+    GDM_CHECK_ARG(go && out, "gdm_wgrad_pack_go_hip: NULL pointer");
+    GDM_CHECK_ARG(shape_ok(B, Cout, H, W), "gdm_wgrad_pack_go_hip: unsupported shape B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
+    GDM_CHECK_ARG(((uintptr_t)out & 15) == 0 && ((uintptr_t)go & 15) == 0, "gdm_wgrad_pack_go_hip: buffers must be 16-byte aligned");
+    const int CoutP = (Cout + 127) & ~127;
+    const long rows = (long)B * (H * W / 128) * CoutP;
+    hipLaunchKernelGGL(wgrad_pack_go_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, go, Cout, CoutP,
+                       H * W, rows, (unsigned char*)out);
+    return gdm_launch_status("wgrad_pack_go_kernel");
+}

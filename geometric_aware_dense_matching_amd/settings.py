@@ -1,6 +1,6 @@
 """Runtime A/B switches of the package, in ONE place.  Every switch selects between a hand-written HIP path and the plain
-form it replaces (the form the parity tests tie it to); all default to the HIP path (USE_SIDE_STREAMS and
-STATIC_MATCH_ROWS are the two that default to off).  They are read at CALL time
+form it replaces (the form the parity tests tie it to); all default to the HIP path (USE_SIDE_STREAMS,
+USE_MFMA_WGRAD and STATIC_MATCH_ROWS are the ones that default to off).  They are read at CALL time
 (`settings.USE_X`), so a test or a benchmark may flip one between two calls; the `GDM_*` environment variables only set
 the initial values.
 
@@ -23,6 +23,8 @@ the initial values.
     USE_SPARSE_FINAL           GDM_SPARSE_FINAL           the last image stage (up_3 + final) on the full 2x map, then the gather with `choose`
                                                           (default: evaluated at the chosen pixels only -- inference, 1/32 of the pixels)
     USE_FUSED_HEADS            GDM_FUSED_HEADS            the nine per-point 1x1 convolutions after the embedding as library GEMMs + BN kernels
+    USE_MFMA_WGRAD             GDM_MFMA_WGRAD=1           (default OFF: MIOpen) weight gradient of the trunk's 3x3 convolutions at Cin = 256 / 512 on the
+                                                          split-bf16 MFMA GEMM: correct, not faster (profiles/r03_negative_results.md)
     USE_GEMM_CONV1X1_TRAIN     GDM_GEMM_CONV1X1_TRAIN     training 1x1 convolutions through torch's convolution (MIOpen wgrad / bwd-data + NHWC transposes)
     USE_OWN_STEM               GDM_OWN_STEM               the stem (conv 7x7/2 + BN + ReLU + max-pool) as an MIOpen convolution + one fused BN/ReLU/pool launch
     USE_POINTWISE              GDM_POINTWISE              per-point 1x1 layers (point branch, fusion, decoder) as library GEMM + BN/activation kernel + torch.cat
@@ -55,13 +57,14 @@ USE_MFMA_STRIDED = _flag("GDM_MFMA_STRIDED")
 USE_POINTWISE = _flag("GDM_POINTWISE")
 USE_OWN_STEM = _flag("GDM_OWN_STEM")
 USE_GEMM_CONV1X1_TRAIN = _flag("GDM_GEMM_CONV1X1_TRAIN")
+USE_MFMA_WGRAD = _flag("GDM_MFMA_WGRAD", "0")
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
-                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN")
+                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN", "USE_MFMA_WGRAD")
 # the switches behind which split-bf16 (x3, fp32 accumulate) products run in the eval forward: all off = fp32 products everywhere
 # (hipBLASLt / MIOpen / fp32 FMA kernels); the matching kernel's precision is its own argument (matching.match_frames(precision=))
 SPLIT_BF16_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED",

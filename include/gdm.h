@@ -478,6 +478,26 @@ int gdm_stem_hip(const float* x, const void* wpk, const float* scale, const floa
                  void* out_packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Weight gradient of a 3x3 / stride 1 / pad 1 convolution on the split-bf16 MFMA GEMM (training; backward of
+ * /root/reference/models/cnn/extractors.py:36-58): dW[co,ci,ky,kx] = sum_{b,y,x} go[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1] is the GEMM
+ * GO (Cout x pixels) . X_tap^T (pixels x Cin).  These two kernels re-lay the operands for gdm_conv1x1_packed_hip: the contraction (its
+ * "Cin") runs over the B*H*W pixels in chunks of 128, its "pixels" are the 9 x Cin grid of (tap, ci), its "weights" the rows of go.
+ *   xpk = gdm_wgrad_pack_x_hip(x f32[B,Cin,H,W])   gdm_wgrad_x_bytes(B,Cin,H,W) bytes (the tap shift applied here, zero outside the map)
+ *   gpk = gdm_wgrad_pack_go_hip(go f32[B,Cout,H,W]) gdm_wgrad_go_bytes(B,Cout,H,W) bytes
+ * then ONE launch of the GEMM with per-image weights, its "images" being P equal parts of n = B*H*W/128/P chunks of the contraction,
+ *   gdm_conv1x1_packed_wb_hip(xpk, gpk, n*CoutP*512, P, 128*n, Cout, 9, Cin, parts, stream)      (9*Cin % 256 == 0)
+ * gives parts f32[P, Cout, 9, Cin]; dW = their sum over P, permuted to [Cout, Cin, 3, 3].  (Or any chunk range [c0, c0+n) alone:
+ * gdm_conv1x1_packed_hip(xpk + c0*32*11*(Cin+2)*16, gpk + c0*CoutP*512, NULL, NULL, 1, 128*n, Cout, 9, Cin, 0, 0, part, stream).)
+ * W in {32, 64}, H*W % 128 == 0, Cin % 32 == 0; CoutP = Cout rounded up to 128.  Both byte counts are 0 for an unsupported shape. */
+size_t gdm_wgrad_x_bytes(int B, int Cin, int H, int W);
+size_t gdm_wgrad_go_bytes(int B, int Cout, int H, int W);
+int gdm_wgrad_pack_x_hip(const float* x, int B, int Cin, int H, int W, void* out, void* stream);
+int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, int W, void* out, void* stream);
+/* gdm_conv1x1_packed_hip without epilogue, NCHW output, with the weights of image b at wpk + b*w_bstride (H*W % 256 == 0). */
+int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long w_bstride, int B, int Cin, int Cout, int H, int W, float* out,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Batched strided copies of 4-byte words (f32 / i32), one launch for a table of views: job i fills the dense array
  * dst[B][R1][R2][E] from src[b*sb + r1*s1 + r2*s2 + e] (strides in words).  The neighbour pyramid uses it for the strided xyz
  * grids (datasets/lm/linemod_pbr.py:517-527: R1 x R2 = rows x columns at stride sr), the prefix sub-clouds (:538) and the pooling

@@ -436,3 +436,21 @@ def test_conv1x1_train_as_batched_gemms_equals_torch_convolution(shape, cout, bi
     want = [y64.detach(), x64.grad, c64.weight.grad] + ([c64.bias.grad] if bias else [])
     for a, b in zip(got, want):
         assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,parts", [(2, 256, 256, 32, 32, None), (3, 256, 64, 32, 32, 4), (1, 512, 136, 8, 64, 1), (2, 256, 256, 64, 64, None)])
+def test_conv3x3_weight_gradient_on_the_mfma_gemm_equals_autograd(B, Cin, Cout, H, W, parts):
+    """ops.conv3x3_wgrad (pixels as the contraction axis of the split-bf16 MFMA GEMM, nine tap-shifted operand copies, K split in parts)
+    == d/dW of conv2d(x, W, padding=1) under fp64 autograd: relative L2 3e-5, max 1e-4 of the gradient's scale."""
+    from geometric_aware_dense_matching_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    go = torch.randn(B, Cout, H, W, generator=g).cuda()
+    assert ops.conv3x3_wgrad_supported(x, go)
+    got = ops.conv3x3_wgrad(x, go, parts=parts)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w, padding=1) * go.double()).sum().backward()
+    want = w.grad
+    assert got.shape == want.shape
+    assert (got.double() - want).norm().item() < 3e-5 * want.norm().item()
+    assert (got.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
