@@ -17,6 +17,7 @@
 // MFMAs, registers -> LDS after them, ONE barrier per panel), 9 * Cin/128 panels accumulate into four 32x32 tiles.
 #include "gdm_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -346,7 +347,9 @@ constexpr int MF_STAGE = 4096 / MF_THREADS;           // 16-byte chunks of a wei
 constexpr int MF_TSTRIDE = 132;                       // floats per pixel row of a wave's output tile in LDS (128 + 4: conflict-free reads)
 constexpr int MF_SMEM = 2 * CV_PANEL > CV_PIX * MF_TSTRIDE * 4 ? 2 * CV_PANEL : CV_PIX * MF_TSTRIDE * 4;
 
-template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8>
+// NCB = 16-channel output blocks per workgroup: 8 (128 channels) or 4 (64 channels: twice the workgroups for the layers whose 128-channel
+// tiling leaves half the chip idle -- layer1-3 of the trunk at batch 16 -- and no zero-padded weight rows for 64-channel layers)
+template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8, int NCB = 8>
 __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
@@ -360,6 +363,10 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     constexpr int NS = NKS / 2;                                     // k-steps of 32 channels per chunk
+    constexpr int NPR = NCB / 2;                                    // pairs of output blocks
+    constexpr int PANEL = NCB * 16 * ROWB;                          // bytes of a weight panel in LDS
+    constexpr int TST = NCB * 16 + 4;                               // floats per pixel row of a wave's output tile in LDS
+    static_assert(NCB == 8 || (NCB == 4 && !PIXMAJOR), "64-channel tiles: NCHW / packed output only");
     constexpr int NPH = MF_NPH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;                      // row inside a 16-row fragment, 8-channel group inside a k-step
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const int hw = H * W;
     const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
     const long pix0 = (long)blockIdx.x * CV_PIX + wave * MF_WPIX;   // this wave's first pixel
-    const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * CV_CO;
+    const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * (NCB * 16);
     const long pc = min(pix0, ptot - MF_WPIX);
     const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
     const int prem = (int)(pc - (long)b * hw);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         }
     };
     // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
-    constexpr int HS = MF_STAGE / 2;
+    constexpr int HS = (NCB * 512 / MF_THREADS) / 2;
     u32x4 stage[HS];
     const unsigned char* wpk_b = wpk + (wbstride ? ((long)blockIdx.x * CV_PIX / hw) * wbstride : 0);
     auto stage_load = [&](int it, int half) {
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         }
     };
     auto stage_store = [&](int buf, int half) {
-        unsigned char* base = smem + buf * CV_PANEL;
+        unsigned char* base = smem + buf * PANEL;
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
             const int g = (half * HS + i) * MF_THREADS + tid;
@@ -420,11 +427,11 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         }
     };
 
-    f32x4 acc[NPH][8];
+    f32x4 acc[NPH][NCB];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[ph][cb][i] = 0.f;
 
@@ -443,13 +450,13 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         const bool more = it + 1 < npanel;
         const unsigned char* rcur = a_row(it);
         const unsigned char* rnext = a_row(more ? it + 1 : it);
-        const unsigned char* base = smem + (it & 1) * CV_PANEL;
+        const unsigned char* base = smem + (it & 1) * PANEL;
         // units of (k-step S, pair of 16-channel output blocks): 6 NPH MFMAs of 16 cycles on 4 B fragments; PF units' reads in flight
         constexpr int PF = 2;
-        constexpr int NU = 4 * NS;
+        constexpr int NU = NPR * NS;
         u32x4 fh[PF + 1][2], fl[PF + 1][2];
         auto frag_load = [&](int un) {
-            const int S = un >> 2, pr = un & 3, slot = un % (PF + 1);
+            const int S = un / NPR, pr = un % NPR, slot = un % (PF + 1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = (2 * pr + j) * 16 + l16;
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         for (int un = 0; un < PF; ++un) frag_load(un);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int S = u >> 2, pr = u & 3, slot = u % (PF + 1);
+            const int S = u / NPR, pr = u % NPR, slot = u % (PF + 1);
             if (u + PF < NU) frag_load(u + PF);
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                     acc[ph][2 * pr + j] = c;
                 }
             }
-            if (pr == 3 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
+            if (pr == NPR - 1 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
             if (u == NU / 2 && more) {                              // the other buffer's readers finished at this panel's barrier
                 stage_store((it + 1) & 1, 0);
                 stage_load(it + 1, 1);
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     if (pix0 >= ptot) return;
     if (PIXMAJOR) {
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
             const int co = co0 + cb * 16 + l16;
             if (co >= Cout) continue;
             const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
@@ -517,10 +524,10 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         }
         return;
     }
-    float* tl = reinterpret_cast<float*>(smem) + wave * MF_WPIX * MF_TSTRIDE;
+    float* tl = reinterpret_cast<float*>(smem) + wave * MF_WPIX * TST;
     if (outpk) __syncthreads();                                      // every wave has finished reading the last weight panel
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int co = co0 + cb * 16 + l16;
         const bool live = co < Cout;
         const float sc = (live && scale) ? scale[co] : 1.f, sh = (live && shift) ? shift[co] : 0.f;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             if (op && live) *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
             if (outpk) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tl[(poff + j) * MF_TSTRIDE + cb * 16 + l16] = live ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) tl[(poff + j) * TST + cb * 16 + l16] = live ? v[j] : 0.f;
             }
         }
     }
@@ -557,13 +564,14 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             const int pp = prem + 32 * half + lr;                    // this lane's pixel of the wave's tile
             const int yy = pp / W, xx = pp - yy * W;
             unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * oplane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
-            const float* row = tl + (32 * half + lr) * MF_TSTRIDE;
+            const float* row = tl + (32 * half + lr) * TST;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int q = 2 * it + h;
-                if (co0 + q * 8 >= Cout) continue;
-                const float4 a0 = *reinterpret_cast<const float4*>(row + q * 8);
-                const float4 a1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+            for (int it = 0; it < NCB; ++it) {
+                const int ql = 2 * it + h;                           // 8-channel group inside this workgroup's channels
+                if (co0 + ql * 8 >= Cout) continue;
+                const int q = (co0 % 128) / 8 + ql;                  // ... and inside the 128-channel chunk of the packed output
+                const float4 a0 = *reinterpret_cast<const float4*>(row + ql * 8);
+                const float4 a1 = *reinterpret_cast<const float4*>(row + ql * 8 + 4);
                 const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 unsigned hi[4], lo[4];
                 split8(v, hi, lo);
@@ -589,6 +597,20 @@ constexpr int CONV_THREADS = CV_THREADS, CONV_WPIX = 32, CONV_SMEM = 2 * CV_PANE
 } // namespace
 
 static bool cin_ok(int Cin) { return Cin == 64 || (Cin >= 128 && Cin % 128 == 0); }
+
+// 64-channel output tiles instead of 128-channel ones: when the 128-channel tiling gives fewer workgroups than the chip has CUs, or
+// the layer has only 64 output channels (GDM_CONV_NCB=8 / 4 forces one form: development)
+static bool narrow_tiles(unsigned pixel_tiles, int Cout)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("GDM_CONV_NCB");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 8) return false;
+    if (forced == 4) return true;
+    return Cout <= 64 || (long)pixel_tiles * ((Cout + 127) / 128) < 256;
+}
 
 extern "C" size_t gdm_conv3x3_act_bytes(int B, int Cin, int H, int W)
 {
@@ -686,6 +708,31 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
 #define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
 #else
 #define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
+#endif
+#if GDM_CONV_SHAPE == 16
+    // 64-channel tiles where 128-channel ones leave the chip half empty (or pad a 64-channel layer with zero rows): twice the workgroups
+    if (narrow_tiles(grid.x, Cout)) {
+        constexpr int SMEM4 = 2 * 64 * ROWB > CV_PIX * 68 * 4 ? 2 * 64 * ROWB : CV_PIX * 68 * 4;
+        const dim3 grid4(grid.x, gdm_cdiv(Cout, 64));
+        static bool attr4 = false;
+#define CV4(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK, 4>), grid4, dim3(CONV_THREADS), SMEM4, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
+#define AT4(A, R, NK) (void)hipFuncSetAttribute((const void*)CONV_KERNEL<A, R, 9, false, NK, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4)
+        if (!attr4) {
+            AT4(0, false, 4); AT4(1, false, 4); AT4(0, true, 4); AT4(1, true, 4);
+            AT4(0, false, 8); AT4(1, false, 8); AT4(0, true, 8); AT4(1, true, 8);
+            attr4 = true;
+        }
+        if (Cin == 64) {
+            if (act == 0) { if (res) CV4(0, true, 4); else CV4(0, false, 4); }
+            else { if (res) CV4(1, true, 4); else CV4(1, false, 4); }
+        } else {
+            if (act == 0) { if (res) CV4(0, true, 8); else CV4(0, false, 8); }
+            else { if (res) CV4(1, true, 8); else CV4(1, false, 8); }
+        }
+#undef CV4
+#undef AT4
+        return gdm_launch_status("conv3x3_bf16x3_kernel (64-channel tiles)");
+    }
 #endif
     if (Cin == 64) {                                             // one half-filled chunk: only its four non-zero k-steps are run
         if (act == 0) { if (res) CV(0, true, 4); else CV(0, false, 4); }
@@ -803,6 +850,21 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
 #undef C1H
         return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
+#if GDM_CONV_SHAPE == 16
+    if (!pixel_major && narrow_tiles(grid.x, Cout)) {
+        const dim3 grid4(grid.x, gdm_cdiv(Cout, 64));
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)CONV_KERNEL<0, false, 1, false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * ROWB);
+            (void)hipFuncSetAttribute((const void*)CONV_KERNEL<1, false, 1, false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * ROWB);
+            attr4 = true;
+        }
+#define C14(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 8, 4>), grid4, dim3(CONV_THREADS), 2 * 64 * ROWB, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
+        if (act == 0) C14(0); else C14(1);
+#undef C14
+        return gdm_launch_status("conv1x1_bf16x3_kernel (64-channel tiles)");
+    }
+#endif
 #define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
     if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }
     else { if (pixel_major) C1(1, true); else C1(1, false); }
