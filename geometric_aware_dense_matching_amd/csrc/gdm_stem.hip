@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                                                    int OH, int OW, int PH, int PW, float* __restrict__ out, unsigned char* __restrict__ outpk)
 {
     __shared__ __attribute__((aligned(16))) float patch[3][SI_H][SI_W];       // 19.9 KB
-    __shared__ __attribute__((aligned(16))) float ct[64][ST_STRIDE];          // 78 KB: relu(bn(conv)) of the 9 x 33 pixels, per channel
+    __shared__ __attribute__((aligned(16))) float ct[32][ST_STRIDE];          // 39 KB: relu(bn(conv)) of the 9 x 33 pixels, 32 channels at a
+                                                                              // time (two passes): 59 KB in all, two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
     const int b = blockIdx.z;
@@ -145,58 +146,61 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         }
     }
 
-    // ---- BN + ReLU, convolution pixels outside the map -> 0 (below every ReLU output a pool window also holds), into LDS ----
-#pragma unroll
-    for (int j = 0; j < MPW; ++j) {
-        if (wave + 4 * j >= SM_FRAGS) continue;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int co = 16 * nf + l16;
-            const float sc = scale[co], sh = shift[co];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = (wave + 4 * j) * 16 + 4 * kg + r;
-                if (p >= SC_PIX) continue;
-                const int cy = p / SC_W, cx = p - cy * SC_W;
-                const int oy = oy0 + cy, ox = ox0 + cx;
-                float v = fmaxf(fmaf(acc[j][nf][r], sc, sh), 0.f);
-                if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) v = 0.f;
-                ct[co][p] = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- max-pool 3x3 / 2 / pad 1: thread = pooled pixel (tid & 63) x 16 channels (wave) ----
+    // ---- BN + ReLU, convolution pixels outside the map -> 0 (below every ReLU output a pool window also holds), into LDS; then the
+    // max-pool 3x3 / 2 / pad 1 with thread = pooled pixel (tid & 63) x 8 channels (wave); two passes of 32 channels ----
     const int pxl = tid & 15, pyl = (tid >> 4) & 3;
     const int py = py0 + pyl, px = px0 + pxl;
-    float pooled[16];
+    const bool store = py < PH && px < PW;
+    const long plane = (long)(PH + 2) * (PW + 2);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float* row = &ct[16 * wave + i][(2 * pyl) * SC_W + 2 * pxl];
-        float m = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();                               // the first pass's readers are done with ct
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int j = 0; j < MPW; ++j) {
+            if (wave + 4 * j >= SM_FRAGS) continue;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, row[dy * SC_W + dx]);
-        pooled[i] = m;
-    }
-    if (py >= PH || px >= PW) return;
-    if (out) {
+            for (int nn = 0; nn < 2; ++nn) {
+                const int nf = 2 * pass + nn;
+                const int co = 16 * nf + l16;
+                const float sc = scale[co], sh = shift[co];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) out[(((long)b * 64 + 16 * wave + i) * PH + py) * PW + px] = pooled[i];
-    }
-    if (outpk) {
-        // packed operand of the next 3x3 convolution (gdm_conv.hip conv_pack_act_kernel's layout, one 64-channel chunk): plane q <
-        // 8 = bf16 hi of channels [8q, 8q + 8), plane 16 + q = their lo; element (py + 1, px + 1) of the zero-bordered grid, 16 B
-        const long plane = (long)(PH + 2) * (PW + 2);
-        unsigned char* ob = outpk + (((long)b * 32) * plane + (long)(py + 1) * (PW + 2) + px + 1) * 16;
+                for (int r = 0; r < 4; ++r) {
+                    const int p = (wave + 4 * j) * 16 + 4 * kg + r;
+                    if (p >= SC_PIX) continue;
+                    const int cy = p / SC_W, cx = p - cy * SC_W;
+                    const int oy = oy0 + cy, ox = ox0 + cx;
+                    float v = fmaxf(fmaf(acc[j][nf][r], sc, sh), 0.f);
+                    if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) v = 0.f;
+                    ct[16 * nn + l16][p] = v;
+                }
+            }
+        }
+        __syncthreads();
+        float pooled[8];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int q = 2 * wave + half;
+        for (int i = 0; i < 8; ++i) {
+            const float* row = &ct[8 * wave + i][(2 * pyl) * SC_W + 2 * pxl];
+            float m = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, row[dy * SC_W + dx]);
+            pooled[i] = m;
+        }
+        if (!store) continue;
+        const int c0 = 32 * pass + 8 * wave;                     // this thread's eight channels
+        if (out) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out[(((long)b * 64 + c0 + i) * PH + py) * PW + px] = pooled[i];
+        }
+        if (outpk) {
+            // packed operand of the next 3x3 convolution (gdm_conv.hip conv_pack_act_kernel's layout, one 64-channel chunk): plane
+            // q < 8 = bf16 hi of channels [8q, 8q + 8), plane 16 + q = their lo; element (py + 1, px + 1) of the zero-bordered grid
+            const int q = c0 / 8;
+            unsigned char* ob = outpk + (((long)b * 32) * plane + (long)(py + 1) * (PW + 2) + px + 1) * 16;
             unsigned hi[4], lo[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) gdm_split2(pooled[8 * half + 2 * jj], pooled[8 * half + 2 * jj + 1], hi[jj], lo[jj]);
+            for (int jj = 0; jj < 4; ++jj) gdm_split2(pooled[2 * jj], pooled[2 * jj + 1], hi[jj], lo[jj]);
             *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
