@@ -286,7 +286,7 @@ class PSPUpsample(nn.Module):
                     return ops.upconv_fused64(x, cache[1], scale, shift, (Hx * 2, Wx * 2), code[0], code[1])
                 if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, 9 * conv.out_channels, Hx * Wx):
                     wpk, c9 = cached_gemm_weight(self, "tap", self._tap_major_weight, (conv.weight,))
-                    z = ops.gemm_bf16x3(x.reshape(Bx, Cin, Hx * Wx), wpk, c9).view(Bx, -1, Hx, Wx)      # split-bf16 MFMA
+                    z = ops.gemm_bf16x3_map(x, wpk, c9)            # split-bf16 MFMA; reads the packed operand its producer wrote, if any
                 else:
                     z = ops.wx(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
                 scale, shift = folded_bn(self.conv[2], conv.bias)

@@ -676,7 +676,12 @@ template <int ACT>
 __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                                                     const int32_t* __restrict__ idx, const float* __restrict__ scale,
                                                                     const float* __restrict__ shift, int C, int n, int m, float slope,
-                                                                    float* __restrict__ y)
+                                                                    float* __restrict__ y,
+                                                                    // optional: the result ALSO as the packed split-bf16 operand of the next
+                                                                    // convolution / GEMM over the [B, C, m / W, W] map (gdm_conv.hip
+                                                                    // conv_pack_act_kernel's layout): a block's 8 channels are one 16-byte
+                                                                    // operand group, so the pack launch that would follow is free here
+                                                                    unsigned char* __restrict__ ypk, int W)
 {
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * 8;
@@ -685,12 +690,30 @@ __global__ __launch_bounds__(256) void gather_add_affine_act_kernel(const float*
     int src = idx[(long)b * m + j];
     src = min(max(src, 0), n - 1);
     const int cend = min(c0 + 8, C);
-    for (int c = c0; c < cend; ++c) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i;
+        if (c >= cend) break;
         const long row = (long)b * C + c;
         float o = scale[c] * (x[row * m + j] + t[row * n + src]) + shift[c];
         if (ACT == 1) o = fmaxf(o, 0.f);
         if (ACT == 2) o = o > 0.f ? o : o * slope;
         y[row * m + j] = o;
+        v[i] = o;
+    }
+    if (ypk) {
+        const int H = m / W, yy = j / W, xx = j - yy * W;
+        const long plane = (long)(H + 2) * (W + 2);
+        const int nchunk = (C + 127) / 128, chunk = c0 / 128, q = (c0 % 128) / 8;
+        unsigned char* o = ypk + ((((long)b * nchunk + chunk) * 32 + q) * plane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gdm_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+        *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + 16 * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
 
@@ -1032,13 +1055,22 @@ extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, cons
 extern "C" int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
                                              int B, int C, int n, int m, int act, float slope, float* y, void* stream)
 {
+    return gdm_gather_add_affine_act2_hip(x, t, idx, scale, shift, B, C, n, m, act, slope, y, nullptr, 0, stream);
+}
+
+extern "C" int gdm_gather_add_affine_act2_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
+                                              int B, int C, int n, int m, int act, float slope, float* y, void* y_packed, int W, void* stream)
+{
+    unsigned char* ypk = (unsigned char*)y_packed;
     GDM_CHECK_ARG(x && t && idx && scale && shift && y, "gdm_gather_add_affine_act_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && C >= 1 && n >= 1 && m >= 1 && act >= 0 && act <= 2, "gdm_gather_add_affine_act_hip: bad shape");
+    GDM_CHECK_ARG(!ypk || (W >= 1 && m % W == 0 && C % 8 == 0 && (C == 64 || C % 128 == 0) && ((uintptr_t)ypk & 15) == 0),
+                  "gdm_gather_add_affine_act2_hip: packed output needs m %% W == 0, C = 64 or a multiple of 128, a 16-byte aligned buffer");
     dim3 grid(gdm_cdiv(m, 256), gdm_cdiv(C, 8), B);
     hipStream_t s = (hipStream_t)stream;
-    if (act == 0) hipLaunchKernelGGL(gather_add_affine_act_kernel<0>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
-    else if (act == 1) hipLaunchKernelGGL(gather_add_affine_act_kernel<1>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
-    else hipLaunchKernelGGL(gather_add_affine_act_kernel<2>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y);
+    if (act == 0) hipLaunchKernelGGL(gather_add_affine_act_kernel<0>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y, ypk, W);
+    else if (act == 1) hipLaunchKernelGGL(gather_add_affine_act_kernel<1>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y, ypk, W);
+    else hipLaunchKernelGGL(gather_add_affine_act_kernel<2>, grid, dim3(256), 0, s, x, t, idx, scale, shift, C, n, m, slope, y, ypk, W);
     return gdm_launch_status("gather_add_affine_act_kernel");
 }
 

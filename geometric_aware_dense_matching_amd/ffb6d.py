@@ -165,8 +165,11 @@ class FFB6DEmb(nn.Module):
                 else:
                     x = ops.wx(wa, rgb_emb0.reshape(bs, c, hr * wr))                    # [B,Cout,HW]
                 scale, shift = folded_bn(fuse_layer.normlayer.bn)
-                y = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1])
-                return y.view(bs, -1, hr, wr)
+                y, ypk = ops.gather_add_affine_act(x, t, idx.reshape(bs, -1), scale, shift, code[0], code[1], hw=(hr, wr))
+                y = y.view(bs, -1, hr, wr)
+                if ypk is not None:
+                    y._gdm_packed = ypk             # the next image stage's first convolution / GEMM reads this: no pack launch
+                return y
         if pixel_major:
             raise RuntimeError("pixel-major fusion output is the eval kernel's; _sparse_final_ok() guards the caller")
         p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)

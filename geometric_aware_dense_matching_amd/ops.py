@@ -866,18 +866,23 @@ def psp_combine(g, ys, bias):
     return g
 
 
-def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0):
+def gather_add_affine_act(x, t, idx, scale, shift, act=ACT_NONE, slope=0.0, hw=None):
     """y[b,c,j] = act(scale[c]*(x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]); x f32[B,C,m], t f32[B,C,n], idx int[B,m(,1)].
-    Inference only, in place on x."""
+    Inference only, in place on x.  With hw = (H, W) of the pixel map (m = H*W) the kernel also writes the packed split-bf16 operand
+    of the next convolution / GEMM over it; the caller hangs the returned PackedAct on the map it hands on (`_gdm_packed`)."""
     x = _dev(x, torch.float32, "x")
     t = _dev(t, torch.float32, "t")
     idx = _idx32(idx, "idx")
     B, C, m = x.shape
     n = t.shape[2]
-    check(_lib.lib().gdm_gather_add_affine_act_hip(x.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                   B, C, n, m, act, float(slope), x.data_ptr(), _stream()),
-          "gdm_gather_add_affine_act_hip")
-    return x
+    opk = None
+    if hw is not None and hw[0] * hw[1] == m and (C == 64 or C % 128 == 0) and hw[1] % 32 == 0 and (B * m) % 256 == 0:
+        opk = PackedAct(_packed_buffer(B, C, hw[0], hw[1], x.device), (B, C, hw[0], hw[1]))
+    check(_lib.lib().gdm_gather_add_affine_act2_hip(x.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                    B, C, n, m, act, float(slope), x.data_ptr(), opk.buf.data_ptr() if opk is not None else None,
+                                                    hw[1] if opk is not None else 0, _stream()),
+          "gdm_gather_add_affine_act2_hip")
+    return (x, opk) if hw is not None else x
 
 
 def lfa_stage(xyz, idx, feat, w1t, s1, b1, w2t, s2, b2, wft, wmt, sm, bm, slope=0.2):
@@ -1188,137 +1193,6 @@ def _capturing_unscoped():
 
 
 
-def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1)):
-    """3x3 / pad 1 / no dilation, stride 1 or 2 (output width a multiple of 32), Cin 64 or a multiple of 128."""
-    cin = weight.shape[1]
-    st = tuple(stride)
-    if st not in ((1, 1), (2, 2)):
-        return False
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-            and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1)
-            and x.shape[2] % st[0] == 0 and x.shape[3] % st[1] == 0 and (x.shape[3] // st[1]) % 32 == 0
-            and (cin == 64 or cin % 128 == 0) and weight.shape[0] % 8 == 0 and x.shape[0] <= 65535)
-
-
-def conv3x3_pack_weight(weight):
-    """w f32[Cout,Cin,3,3] -> packed split-bf16 rows (u8 tensor); cache it per weight version."""
-    weight = _dev(weight.detach(), torch.float32, "weight")
-    Cout, Cin = weight.shape[0], weight.shape[1]
-    L = _lib.lib()
-    wpk = torch.empty(L.gdm_conv3x3_weight_bytes(Cout, Cin), dtype=torch.uint8, device=weight.device)
-    check(L.gdm_conv3x3_pack_weight_hip(weight.data_ptr(), Cout, Cin, wpk.data_ptr(), _stream()), "gdm_conv3x3_pack_weight_hip")
-    return wpk
-
-
-class PackedAct:
-    """An activation map in the convolution kernel's operand layout (bf16 hi / lo planes of 8 channels, one-pixel zero border):
-    what conv3x3_bf16x3(..., out_packed=True) hands to the next convolution instead of a pack launch."""
-    __slots__ = ("buf", "shape")
-
-    def __init__(self, buf, shape):
-        self.buf, self.shape = buf, tuple(shape)
-
-
-def _packed_buffer(B, C, H, W, device, avoid=None):
-    """Zero-bordered operand buffer for [B,C,H,W] from the current BufferPool (two per shape and stream: a layer reads one and
-    writes the other).  Only interior pixels are ever written, so the border stays zero."""
-    nbytes = _lib.lib().gdm_conv3x3_act_bytes(B, C, H, W)
-    if _capturing_unscoped():
-        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    key = (B, C, H, W, device.index, torch.cuda.current_stream().cuda_stream)
-    pool = _pool.packed.setdefault(key, [])
-    for buf in pool:
-        if avoid is None or buf.data_ptr() != avoid.data_ptr():
-            return buf
-    buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    pool.append(buf)
-    return buf
-
-
-def conv3x3_pack_act(x):
-    """x f32[B,C,H,W] -> PackedAct (one launch)."""
-    x = _dev(x, torch.float32, "x")
-    B, C, H, W = x.shape
-    buf = _packed_buffer(B, C, H, W, x.device)
-    check(_lib.lib().gdm_conv3x3_pack_act_hip(x.data_ptr(), B, C, H, W, buf.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
-    return PackedAct(buf, (B, C, H, W))
-
-
-def conv3x3_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, res=None, out_f32=True, out_packed=False, stride=1):
-    """3x3/p1 convolution (stride 1 or 2) of x f32[B,Cin,H,W] (or a PackedAct) with packed weights on split-bf16 MFMA (+ per-channel
-    scale/shift, optional residual, optional ReLU).  Returns the fp32 map, or -- out_packed -- (fp32 map or None, PackedAct of the
-    result): the epilogue writes the next convolution's operand itself.  Inference only."""
-    xp = x if isinstance(x, PackedAct) else conv3x3_pack_act(x)
-    B, Cin, H, W = xp.shape
-    if stride != 1:
-        if stride != 2 or H % 2 or W % 2:
-            raise ValueError("conv3x3_bf16x3: stride %r on a %dx%d map" % (stride, H, W))
-        H, W = H // 2, W // 2
-    L = _lib.lib()
-    dev = xp.buf.device
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev) if out_f32 else None
-    opk = None
-    if out_packed:
-        if (B * H * W) % 256 != 0 or cout % 8 != 0:
-            raise ValueError("conv3x3_bf16x3: packed output needs B*H*W %% 256 == 0 and Cout %% 8 == 0")
-        opk = PackedAct(_packed_buffer(B, cout, H, W, dev, avoid=xp.buf), (B, cout, H, W))
-    if res is not None:
-        res = _dev(res, torch.float32, "res")
-        assert tuple(res.shape) == (B, cout, H, W)
-    check(L.gdm_conv3x3_strided_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                    shift.data_ptr() if shift is not None else None, res.data_ptr() if res is not None else None,
-                                    B, Cin, cout, H, W, int(stride), act, out.data_ptr() if out is not None else None,
-                                    opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_conv3x3_strided_hip")
-    return (out, opk) if out_packed else out
-
-
-def gemm_bf16x3_map(x, wpk, cout):
-    """W @ x over the channels of a map x f32[B,Cin,H,W] -> f32[B,cout,H,W] on split-bf16 MFMA.  If x carries the packed operand its
-    producer wrote (`_gdm_packed`, the trunk's residual blocks), the GEMM reads that and no pack launch is needed."""
-    B, Cin, H, W = x.shape
-    xp = getattr(x, "_gdm_packed", None)
-    if isinstance(xp, PackedAct) and xp.shape == (B, Cin, H, W) and W % 32 == 0:
-        return conv1x1_packed2d(xp, wpk, cout)
-    return gemm_bf16x3(x.reshape(B, Cin, H * W), wpk, cout).view(B, cout, H, W)
-
-
-def conv1x1_packed2d(xp, wpk, cout, scale=None, shift=None, act=ACT_NONE, stride=1):
-    """1x1 convolution (stride 1 or 2) of a PackedAct map with gemm_pack_weight'ed weights -> f32[B,cout,H/stride,W/stride]: the
-    downsample branch of a residual block on the packed operand its 3x3 convolution already reads.  Inference only."""
-    B, Cin, H, W = xp.shape
-    if stride not in (1, 2) or H % stride or W % stride:
-        raise ValueError("conv1x1_packed2d: stride %r on a %dx%d map" % (stride, H, W))
-    H, W = H // stride, W // stride
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=xp.buf.device)
-    check(_lib.lib().gdm_conv1x1_strided_hip(xp.buf.data_ptr(), wpk.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                             shift.data_ptr() if shift is not None else None, B, Cin, cout, H, W, int(stride), act,
-                                             out.data_ptr(), _stream()), "gdm_conv1x1_strided_hip")
-    return out
-
-
-class _Conv3x3Train(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight):
-        ctx.save_for_backward(x, weight)
-        return conv3x3_bf16x3(x, conv3x3_pack_weight(weight), weight.shape[0])
-
-    @staticmethod
-    def backward(ctx, go):
-        x, weight = ctx.saved_tensors
-        go = _dev(go, torch.float32, "grad")
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            # dgrad of a 3x3/s1/p1 convolution = the same convolution of grad_out with the flipped, transposed filter
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
-            gx = conv3x3_bf16x3(go, conv3x3_pack_weight(wt), weight.shape[1])
-        if ctx.needs_input_grad[1]:
-            if conv3x3_wgrad_supported(x, go):
-                gw = conv3x3_wgrad(x, go)
-            else:
-                gw = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return gx, gw
-
-
 def conv3x3_wgrad_supported(x, go):
     """The split-bf16 MFMA weight-gradient path: 32- or 64-wide maps, Cin a multiple of 256 (the per-part weights of the GEMM want
     whole 256-row tiles per part) -- the 32 x 32 half of the trunk, where torch's path (MIOpen fp32 implicit GEMM) is 2.5x slower."""
@@ -1492,46 +1366,6 @@ class _Conv3x3Train(torch.autograd.Function):
             else:
                 gw = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return gx, gw
-
-
-def conv3x3_wgrad_supported(x, go):
-    B, Cin, H, W = x.shape
-    return (settings.USE_MFMA_WGRAD and x.is_cuda and x.dtype == torch.float32 and go.shape[0] == B and tuple(go.shape[2:]) == (H, W)
-            and W in (32, 64) and (H * W) % 128 == 0 and Cin % 32 == 0 and go.shape[1] % 8 == 0)
-
-
-def conv3x3_wgrad(x, go, parts=None):
-    """dW f32[Cout,Cin,3,3] of a 3x3 / stride 1 / pad 1 convolution from its input x f32[B,Cin,H,W] and output gradient go
-    f32[B,Cout,H,W], on the split-bf16 MFMA GEMM (include/gdm.h gdm_wgrad_*): the contraction runs over the B*H*W pixels, split
-    into `parts` launches whose [Cout,9,Cin] partial products are added here (a fixed order: deterministic)."""
-    x = _dev(x, torch.float32, "x")
-    go = _dev(go, torch.float32, "grad_out")
-    B, Cin, H, W = x.shape
-    Cout = go.shape[1]
-    L = _lib.lib()
-    nx, ng = L.gdm_wgrad_x_bytes(B, Cin, H, W), L.gdm_wgrad_go_bytes(B, Cout, H, W)
-    if nx == 0 or ng == 0:
-        raise ValueError("conv3x3_wgrad: unsupported shape x %s grad_out %s" % (tuple(x.shape), tuple(go.shape)))
-    xpk = torch.empty(nx, dtype=torch.uint8, device=x.device)
-    gpk = torch.empty(ng, dtype=torch.uint8, device=x.device)
-    check(L.gdm_wgrad_pack_x_hip(x.data_ptr(), B, Cin, H, W, xpk.data_ptr(), _stream()), "gdm_wgrad_pack_x_hip")
-    check(L.gdm_wgrad_pack_go_hip(go.data_ptr(), B, Cout, H, W, gpk.data_ptr(), _stream()), "gdm_wgrad_pack_go_hip")
-    nchunk = B * H * W // 128
-    if parts is None:
-        # enough workgroups to fill the chip: a launch has ceil(9 Cin / 256) x ceil(Cout / 128) of them
-        tiles = ((9 * Cin + 255) // 256) * ((Cout + 127) // 128)
-        parts = max(1, min(nchunk, (320 + tiles - 1) // tiles))
-    coutp = (Cout + 127) // 128 * 128
-    xstep, gstep = 32 * 11 * (Cin + 2) * 16, coutp * 512
-    out = torch.empty((parts, Cout, 9, Cin), dtype=torch.float32, device=x.device)
-    c0 = 0
-    for p in range(parts):
-        n = nchunk // parts + (1 if p < nchunk % parts else 0)
-        check(L.gdm_conv1x1_packed_hip(xpk.data_ptr() + c0 * xstep, gpk.data_ptr() + c0 * gstep, None, None, 1, 128 * n, Cout, 9, Cin, 0, 0,
-                                       out[p].data_ptr(), _stream()), "gdm_conv1x1_packed_hip (wgrad)")
-        c0 += n
-    dw = out[0] if parts == 1 else out.sum(0)
-    return dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
 
 
 def conv3x3_train(x, weight):

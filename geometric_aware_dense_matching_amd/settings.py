@@ -1,6 +1,6 @@
 """Runtime A/B switches of the package, in ONE place.  Every switch selects between a hand-written HIP path and the plain
-form it replaces (the form the parity tests tie it to); all default to the HIP path (USE_SIDE_STREAMS,
-USE_MFMA_WGRAD and STATIC_MATCH_ROWS are the ones that default to off).  They are read at CALL time
+form it replaces (the form the parity tests tie it to); all default to the HIP path (USE_SIDE_STREAMS and
+STATIC_MATCH_ROWS are the two that default to off).  They are read at CALL time
 (`settings.USE_X`), so a test or a benchmark may flip one between two calls; the `GDM_*` environment variables only set
 the initial values.
 
@@ -23,8 +23,7 @@ the initial values.
     USE_SPARSE_FINAL           GDM_SPARSE_FINAL           the last image stage (up_3 + final) on the full 2x map, then the gather with `choose`
                                                           (default: evaluated at the chosen pixels only -- inference, 1/32 of the pixels)
     USE_FUSED_HEADS            GDM_FUSED_HEADS            the nine per-point 1x1 convolutions after the embedding as library GEMMs + BN kernels
-    USE_MFMA_WGRAD             GDM_MFMA_WGRAD=1           (default OFF: MIOpen) weight gradient of the trunk's 3x3 convolutions at Cin = 256 / 512 on the
-                                                          split-bf16 MFMA GEMM: correct, not faster (profiles/r03_negative_results.md)
+    USE_MFMA_WGRAD             GDM_MFMA_WGRAD             weight gradient of the trunk's 3x3 convolutions at Cin = 256 / 512 on MIOpen (fp32 implicit GEMM)
     USE_GEMM_CONV1X1_TRAIN     GDM_GEMM_CONV1X1_TRAIN     training 1x1 convolutions through torch's convolution (MIOpen wgrad / bwd-data + NHWC transposes)
     USE_OWN_STEM               GDM_OWN_STEM               the stem (conv 7x7/2 + BN + ReLU + max-pool) as an MIOpen convolution + one fused BN/ReLU/pool launch
     USE_POINTWISE              GDM_POINTWISE              per-point 1x1 layers (point branch, fusion, decoder) as library GEMM + BN/activation kernel + torch.cat
@@ -57,7 +56,7 @@ USE_MFMA_STRIDED = _flag("GDM_MFMA_STRIDED")
 USE_POINTWISE = _flag("GDM_POINTWISE")
 USE_OWN_STEM = _flag("GDM_OWN_STEM")
 USE_GEMM_CONV1X1_TRAIN = _flag("GDM_GEMM_CONV1X1_TRAIN")
-USE_MFMA_WGRAD = _flag("GDM_MFMA_WGRAD", "0")
+USE_MFMA_WGRAD = _flag("GDM_MFMA_WGRAD")
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))

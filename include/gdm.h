@@ -335,6 +335,10 @@ int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2
  * x f32[B,C,m] (pixel half of the 1x1 conv), t f32[B,C,n] (point half, computed at the points), idx i32[B,m]. May run in place. */
 int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
                                   int B, int C, int n, int m, int act, float slope, float* y, void* stream);
+/* ... and, with y_packed != NULL, the result ALSO as the packed split-bf16 operand of the next convolution / GEMM over the
+ * [B, C, m/W, W] map (gdm_conv3x3_act_bytes(B, C, m/W, W) bytes, zero border in place): no pack launch in front of that layer. */
+int gdm_gather_add_affine_act2_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,
+                                   int B, int C, int n, int m, int act, float slope, float* y, void* y_packed, int W, void* stream);
 /* The same tail with the pixel half of the 1x1 convolution inside, for the 64-channel levels (C == 64):
  * y[b,co,j] = act(scale[co]*(sum_ci W[co,ci] x[b,ci,j] + t[b,co,idx[b,j]]) + shift[co]); wt f32[C,C] = W transposed ([ci][co]). */
 int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,

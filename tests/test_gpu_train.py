@@ -446,12 +446,7 @@ def test_conv3x3_weight_gradient_on_the_mfma_gemm_equals_autograd(B, Cin, Cout, 
     g = torch.Generator(device="cpu").manual_seed(Cin + Cout + H)
     x = torch.randn(B, Cin, H, W, generator=g).cuda()
     go = torch.randn(B, Cout, H, W, generator=g).cuda()
-    saved = settings.USE_MFMA_WGRAD
-    settings.USE_MFMA_WGRAD = True                     # off by default (profiles/r03_negative_results.md): correct, not faster
-    try:
-        assert ops.conv3x3_wgrad_supported(x, go)
-    finally:
-        settings.USE_MFMA_WGRAD = saved
+    assert ops.conv3x3_wgrad_supported(x, go)
     got = ops.conv3x3_wgrad(x, go, parts=parts)
     w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
     (torch.nn.functional.conv2d(x.double(), w, padding=1) * go.double()).sum().backward()
