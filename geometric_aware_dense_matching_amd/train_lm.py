@@ -75,6 +75,10 @@ def build_parser():
     p.add_argument("--single-object", action="store_true", help="test: only -cls_id instead of every object of the dataset")
     p.add_argument("--graph-batch1", action="store_true",
                    help="test: per-object hipGraph replay for single-instance groups (a batch-1 eager step is launch-bound)")
+    p.add_argument("--objects-across-gpus", action="store_true",
+                   help="train: the dataset's objects are independent jobs (train_ycb.sh:3-9 runs them one after the other): rank r of a "
+                        "torch.distributed.run launch trains objects r, r + world, ... on its own GPU as single-process jobs -- no process "
+                        "group, no collective")
     p.add_argument("--graph-train", action="store_true",
                    help="train: capture one iteration (forward + losses + backward + Adam) as a hipGraph and replay it (single process)")
     return p
@@ -249,7 +253,32 @@ def obj_name_of(ds, cls_id):
     return ds["objs"].get(cls_id, "obj_%02d" % cls_id)
 
 
+def object_shard(cls_ids, rank, world):
+    """Objects of rank `rank` under --objects-across-gpus: every world-th object of the sorted id list (disjoint, covering)."""
+    return sorted(cls_ids)[rank::world]
+
+
+def train_objects_across_gpus(args):
+    """The zero-communication sharding of BASELINE config 3: the 21 YCB-V (8 LM-O) objects are independent training jobs
+    (/root/reference/train_ycb.sh:3-9), so each rank of the launch trains its share of them alone on its GPU.  Returns
+    {cls_id: Trainer}."""
+    import copy
+    from .parallel import env_rank
+    rank, local_rank, world = env_rank()
+    ds = dataset_config(args.dataset_name)
+    mine = object_shard(ds["objs"], rank, world)
+    out = {}
+    for cid in mine:
+        a = copy.copy(args)
+        a.cls_id, a.local_rank, a.objects_across_gpus, a._single_process = cid, local_rank, False, True
+        print("[rank %d/%d] training object %d (%s)" % (rank, world, cid, obj_name_of(ds, cid)), flush=True)
+        out[cid] = train(a)
+    return out
+
+
 def train(args):
+    if getattr(args, "objects_across_gpus", False):
+        return train_objects_across_gpus(args)
     torch.backends.cudnn.benchmark = not args.deterministic
     if args.deterministic:                                    # train_lm.py:377-381
         torch.backends.cudnn.deterministic = True
@@ -259,7 +288,10 @@ def train(args):
     log_dir = args.log_dir or ds["checkpoints"]
     device = torch.device("cuda", args.local_rank)
     torch.cuda.set_device(device)
-    rank, local_rank, world = init_distributed("nccl", device)
+    if getattr(args, "_single_process", False):
+        rank, local_rank, world = 0, args.local_rank, 1       # one object per rank: no process group (--objects-across-gpus)
+    else:
+        rank, local_rank, world = init_distributed("nccl", device)
     train_ds = make_dataset(args, "train")
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds) if world > 1 else None
     loader = torch.utils.data.DataLoader(train_ds, batch_size=batch_size, shuffle=sampler is None, drop_last=True,
@@ -284,8 +316,9 @@ def train(args):
                                                      step_size_up=steps, step_size_down=steps, mode="triangular")
     bnm = BNMomentumScheduler(model, lambda i: max(args.bn_momentum * args.bn_decay ** int(i * batch_size / args.decay_step),
                                                    bnm_clip), last_epoch=it)
-    trainer = Trainer(model, optimizer, log_dir, obj_name, lr_scheduler, bnm, device, local_rank, args.save_every, args.log_every,
-                      graphed_step=graphed)
+    trainer = Trainer(model, optimizer, log_dir, obj_name, lr_scheduler, bnm, device,
+                      0 if getattr(args, "_single_process", False) else local_rank,     # an objects-across-gpus rank logs / saves its own objects
+                      args.save_every, args.log_every, graphed_step=graphed)
     trainer.train(start_epoch, args.epochs, loader, sampler, max_iters=args.max_iters)
     return trainer
 

@@ -186,3 +186,19 @@ def test_entry_points_select_dataset_and_variant():
         train_lm.build_model(train_lm.build_parser().parse_args("-cls_id=16 --n-mesh 64".split()), 16)   # not a LineMOD object
     d = train_lm.build_model(train_ycb.build_parser().parse_args("-cls_id=16 --n-mesh 64 --model-variant dgcnn".split()), 16)
     assert type(d).__module__.endswith("geoMatch_DGCNN") and d.needs_pyramid is False
+
+
+def test_objects_across_gpus_shards_are_disjoint_and_cover_every_object():
+    """--objects-across-gpus (train_ycb.sh:3-9 runs the 21 YCB-V objects as independent jobs): every object belongs to exactly one rank,
+    for every world size the driver uses."""
+    from geometric_aware_dense_matching_amd import config, train_lm
+    for name, n in (("ycbv", 21), ("lmo", 8)):
+        ids = list(config.dataset_config(name)["objs"])
+        assert len(ids) == n
+        for world in (1, 2, 4, 8):
+            shards = [train_lm.object_shard(ids, r, world) for r in range(world)]
+            flat = [c for s in shards for c in s]
+            assert sorted(flat) == sorted(ids) and len(set(flat)) == n
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    a = train_lm.build_parser().parse_args(["--objects-across-gpus"])
+    assert a.objects_across_gpus
