@@ -358,7 +358,12 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                                                                  unsigned char* __restrict__ outpk = nullptr, int stride = 1,
                                                                  // per-image weights (the weight-gradient GEMM: image b of a workgroup's 256 pixels --
                                                                  // H*W % 256 == 0 -- reads its rows at wpk + b * wbstride); 0 = shared weights
-                                                                 long wbstride = 0)
+                                                                 long wbstride = 0,
+                                                                 // 1: the grid is (channel tiles, pixel tiles) -- consecutive workgroups share
+                                                                 // a pixel tile, so a layer with many channel tiles streams its activations
+                                                                 // once instead of once per round of channel tiles (PMC: 412 -> ~120 MB for
+                                                                 // the 1024 -> 2304 tap GEMM)
+                                                                 int co_fastest = 0)
 {
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const int npanel = TAPS * nchunk;
     const int hw = H * W;
     const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
-    const long pix0 = (long)blockIdx.x * CV_PIX + wave * MF_WPIX;   // this wave's first pixel
-    const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * (NCB * 16);
+    const unsigned bx = co_fastest ? blockIdx.y : blockIdx.x, by = co_fastest ? blockIdx.x : blockIdx.y;
+    const long pix0 = (long)bx * CV_PIX + wave * MF_WPIX;           // this wave's first pixel
+    const int co0 = tile_co0 ? tile_co0[bx] : by * (NCB * 16);
     const long pc = min(pix0, ptot - MF_WPIX);
     const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
     const int prem = (int)(pc - (long)b * hw);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
     constexpr int HS = (NCB * 512 / MF_THREADS) / 2;
     u32x4 stage[HS];
-    const unsigned char* wpk_b = wpk + (wbstride ? ((long)blockIdx.x * CV_PIX / hw) * wbstride : 0);
+    const unsigned char* wpk_b = wpk + (wbstride ? ((long)bx * CV_PIX / hw) * wbstride : 0);
     auto stage_load = [&](int it, int half) {
         const unsigned char* src = wpk_b + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
@@ -827,7 +833,13 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
                   "gdm_conv1x1_packed_hip: W=%d must be a multiple of 32 and H*W=%d of %d", W, H * W, CONV_WPIX);
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
-    dim3 grid(gdm_cdiv(ptot, CV_PIX), gdm_cdiv(Cout, CV_CO));       // the last block's rows beyond Cout are zero weights, never stored
+    const unsigned ptiles = gdm_cdiv(ptot, CV_PIX);
+    const bool narrow = (GDM_CONV_SHAPE == 16) && Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
+    const unsigned ctiles = gdm_cdiv(Cout, narrow ? 64 : CV_CO);    // the last block's rows beyond Cout are zero weights, never stored
+    // many channel tiles: channel tile = the fast grid axis (see the kernel's co_fastest)
+    static const int co_env = getenv("GDM_CONV_CO_FASTEST") ? atoi(getenv("GDM_CONV_CO_FASTEST")) : -1;
+    const int co_fast = (GDM_CONV_SHAPE == 16) && (co_env >= 0 ? co_env : (int)(ctiles >= 8 && ptiles <= 65535));
+    const dim3 grid = co_fast ? dim3(ctiles, ptiles) : dim3(ptiles, ctiles);
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
@@ -841,7 +853,7 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     }
     if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
 #if GDM_CONV_SHAPE == 16
-#define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride
+#define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride, 0L, co_fast
 #else
 #define C1TAIL
 #endif
@@ -851,8 +863,8 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
         return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
 #if GDM_CONV_SHAPE == 16
-    if (!pixel_major && narrow_tiles(grid.x, Cout)) {
-        const dim3 grid4(grid.x, gdm_cdiv(Cout, 64));
+    if (narrow) {
+        const dim3 grid4 = grid;
         static bool attr4 = false;
         if (!attr4) {
             (void)hipFuncSetAttribute((const void*)CONV_KERNEL<0, false, 1, false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * ROWB);
