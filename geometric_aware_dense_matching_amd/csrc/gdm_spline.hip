@@ -174,6 +174,81 @@ __global__ __launch_bounds__(128) void spline_direct_kernel(const float* __restr
     }
 }
 
+// The same with FOUR output channels per thread (C % 4 == 0): the kernel is bound by its weight loads (4 edges x 8 corners x Cin rows
+// per output channel, L2 hits), and a 16-byte load costs the memory path what a 4-byte one does -- a quarter of the load instructions
+// and of the threads.  A 128-thread block owns 512 / C vertices.
+template <bool RELU, int CIN_MAX>
+__global__ __launch_bounds__(128) void spline_direct_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                                const float* __restrict__ attr, const float* __restrict__ root_t,
+                                                                const float* __restrict__ bias, int M, int Cin, int C, int KS,
+                                                                float* __restrict__ out)
+{
+    const int tpv = C / 4;                                        // threads per vertex
+    const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
+    const int o = (threadIdx.x % tpv) * 4;
+    if (i >= M) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; ++e) {
+        const int j = src[e];
+        float xj[CIN_MAX];
+#pragma unroll
+        for (int q = 0; q < CIN_MAX; ++q) xj[q] = q < Cin ? x[(long)j * Cin + q] : 0.f;
+        float fr[3];
+        int fl[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = attr[3 * e + d] * (float)(KS - 1);     // open spline, degree 1
+            const float f = floorf(v);
+            fl[d] = (int)f;
+            fr[d] = v - f;
+        }
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int wi = 0, off = 1;
+            float b = 1.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int kd = (s >> d) & 1;
+                wi += ((fl[d] + kd) % KS) * off;
+                off *= KS;
+                b *= kd ? fr[d] : 1.f - fr[d];
+            }
+            const float* wr = w + (long)wi * Cin * C + o;
+            float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < CIN_MAX; ++q)
+                if (q < Cin) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wr + (long)q * C);
+                    dot.x = fmaf(xj[q], wv.x, dot.x); dot.y = fmaf(xj[q], wv.y, dot.y);
+                    dot.z = fmaf(xj[q], wv.z, dot.z); dot.w = fmaf(xj[q], wv.w, dot.w);
+                }
+            m.x += b * dot.x; m.y += b * dot.y; m.z += b * dot.z; m.w += b * dot.w;
+        }
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    }
+    const int deg = e1 - e0;
+    float4 r = deg > 0 ? make_float4(acc.x / (float)deg, acc.y / (float)deg, acc.z / (float)deg, acc.w / (float)deg)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (root_t) {
+        float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < Cin; ++q) {
+            const float xv = x[(long)i * Cin + q];
+            const float4 wv = *reinterpret_cast<const float4*>(root_t + (long)q * C + o);
+            dot.x = fmaf(xv, wv.x, dot.x); dot.y = fmaf(xv, wv.y, dot.y); dot.z = fmaf(xv, wv.z, dot.z); dot.w = fmaf(xv, wv.w, dot.w);
+        }
+        r.x += dot.x; r.y += dot.y; r.z += dot.z; r.w += dot.w;
+    }
+    if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + o);
+        r.x += bv.x; r.y += bv.y; r.z += bv.z; r.w += bv.w;
+    }
+    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+}
+
 // Aggregation for the edge-grouped form: Y f32[R,128-wide rows of C] holds x_j . W[wi] for every (source, kernel index) pair that
 // some edge needs (gdm_gemm_grouped_hip); pos i32[E,8] = row of Y for (edge, corner), basis f32[E,8] the corner weights.
 template <bool RELU>
@@ -201,6 +276,44 @@ __global__ __launch_bounds__(128) void spline_pairs_aggregate_kernel(const float
     }
 }
 
+// four output channels per thread (C % 4 == 0): 16-byte loads of the Y rows, a block owns 512 / C vertices
+template <bool RELU>
+__global__ __launch_bounds__(128) void spline_pairs_aggregate_vec_kernel(const float* __restrict__ Y, const int32_t* __restrict__ rowptr,
+                                                                         const int32_t* __restrict__ pos, const float* __restrict__ basis,
+                                                                         const float* __restrict__ root, const float* __restrict__ bias,
+                                                                         int M, int C, float* __restrict__ out)
+{
+    const int tpv = C / 4;
+    const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
+    const int o = (threadIdx.x % tpv) * 4;
+    if (i >= M) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; ++e) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float b = basis[8 * e + s];
+            const float4 y = *reinterpret_cast<const float4*>(Y + (long)pos[8 * e + s] * C + o);
+            m.x += b * y.x; m.y += b * y.y; m.z += b * y.z; m.w += b * y.w;
+        }
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    }
+    const int deg = e1 - e0;
+    float4 r = deg > 0 ? make_float4(acc.x / (float)deg, acc.y / (float)deg, acc.z / (float)deg, acc.w / (float)deg)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (root) {
+        const float4 v = *reinterpret_cast<const float4*>(root + (long)i * C + o);
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    if (bias) {
+        const float4 v = *reinterpret_cast<const float4*>(bias + o);
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+}
+
 } // namespace
 
 extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
@@ -208,6 +321,15 @@ extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* row
 {
     GDM_CHECK_ARG(Y && rowptr && pos && basis && out, "gdm_spline_pairs_aggregate_hip: NULL pointer");
     GDM_CHECK_ARG(M >= 1 && C >= 1, "gdm_spline_pairs_aggregate_hip: bad shape");
+    if (C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!root || ((uintptr_t)root & 15) == 0) &&
+        (!bias || ((uintptr_t)bias & 15) == 0)) {
+        const dim3 grid(gdm_cdiv(M, 128 / (C / 4)));
+        if (relu)
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out);
+        else
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out);
+        return gdm_launch_status("spline_pairs_aggregate_vec_kernel");
+    }
     if (relu)
         hipLaunchKernelGGL(spline_pairs_aggregate_kernel<true>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
     else
@@ -221,6 +343,19 @@ extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const 
 {
     GDM_CHECK_ARG(x && weight && rowptr && src && attr && out, "gdm_spline_direct_hip: NULL pointer");
     GDM_CHECK_ARG(M >= 1 && C >= 1 && kernel_size >= 2 && Cin >= 1 && Cin <= 16, "gdm_spline_direct_hip: bad shape M=%d Cin=%d (<= 16) C=%d ks=%d", M, Cin, C, kernel_size);
+    const bool vec = C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)weight & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     (!root_t || ((uintptr_t)root_t & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+    if (vec) {
+        const int vpb = 128 / (C / 4);                            // vertices per block
+        const dim3 grid(gdm_cdiv(M, vpb));
+        if (relu)
+            hipLaunchKernelGGL((spline_direct_vec_kernel<true, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
+                               bias, M, Cin, C, kernel_size, out);
+        else
+            hipLaunchKernelGGL((spline_direct_vec_kernel<false, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
+                               bias, M, Cin, C, kernel_size, out);
+        return gdm_launch_status("spline_direct_vec_kernel");
+    }
     if (relu)
         hipLaunchKernelGGL((spline_direct_kernel<true, 16>), dim3(M), dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t, bias, Cin, C, kernel_size, out);
     else
