@@ -124,6 +124,31 @@ def timed(fn, n, torch):
     return a.elapsed_time(b) / n
 
 
+def timed_launches(fn, n, torch):
+    """Average ms of n back-to-back launches of fn, captured in ONE hipGraph and replayed between two events (the kernels and their
+    ~1.5 us dependent-launch boundaries, not the host's enqueue cadence); falls back to the eager loop."""
+    from geometric_aware_dense_matching_amd import ops
+    try:
+        with ops.buffer_pool(ops.BufferPool()):
+            fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    fn()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+    except Exception:                                            # noqa: BLE001
+        torch.cuda.synchronize()
+        return timed(fn, n, torch)
+
+
 def kernel_rooflines(torch, dev, B, N):
     """Live HIP-event timings of the kernels that dominate the step besides the matching kernel, at the shapes the step
     launches them with; each entry states its algorithmic work and the peak it is priced against."""
@@ -131,6 +156,14 @@ def kernel_rooflines(torch, dev, B, N):
     L = _lib.lib()
     out = []
     n = 20
+    try:                                                        # HBM-side bytes per launch from the committed PMC passes (headline shape)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"] if (B, N) == (16, 2048) else {}
+    except Exception:                                           # noqa: BLE001
+        pmc = {}
+
+    def traffic(*patterns):
+        vals = [pmc[p]["bytes_per_launch"] for p in patterns if p in pmc]
+        return sum(vals) if len(vals) == len(patterns) else None
     # (1) trunk 3x3 convolution 512 -> 512 at 32 x 32 (ResNet-18 layer4, extractors.py:36-58), kernel alone on packed operands
     Cin = Cout = 512
     H = W = 32
@@ -144,11 +177,12 @@ def kernel_rooflines(torch, dev, B, N):
                                                        o.data_ptr(), ops._stream()), "conv")
     for _ in range(3):
         conv()
-    ms = timed(conv, n, torch)
+    ms = timed_launches(conv, n, torch)
     fl = 2.0 * 9 * Cin * Cout * B * H * W
     out.append({"kernel": "conv_mfma16_kernel 3x3 512->512 @32x32 (trunk layer4)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
-                "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4), "traffic": None,
+                "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
+                "traffic": traffic("conv_mfma16_kernel<0, false, 9, false, 8, 8>"),
                 "work": "2*9*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * H * W)})
     # (2) neighbour pyramid, K = 16 searches (knn_wave_kernel): pair evaluations per second against the vector-ALU bound
     batch = synthetic.make_batch(seed=100, batch=B, n_points=N)
@@ -156,7 +190,7 @@ def kernel_rooflines(torch, dev, B, N):
     xyz = torch.from_numpy(batch["dpt_xyz"]).to(dev)
     for _ in range(3):
         pyramid.build_pyramid(cld, xyz)
-    ms = timed(lambda: pyramid.build_pyramid(cld, xyz), n, torch)
+    ms = timed_launches(lambda: pyramid.build_pyramid(cld, xyz), n, torch)
     S2 = 256 * 256
     lv = [N, N // 4, N // 16, N // 64, N // 256]
     pairs = 0
@@ -168,7 +202,8 @@ def kernel_rooflines(torch, dev, B, N):
     valu_peak = 256 * 4 * 32 * 2.4e9 / 9.0 / 1e12        # 9 vector ops per pair (3 sub, 3 mul, 2 add, 1 compare)
     out.append({"kernel": "knn_wave_kernel + knn_grid_kernel + knn_kernel<1> (+ pack / range kernels): whole neighbour pyramid, 22 searches per crop", "bound": "valu",
                 "unit": "Tpair/s", "achieved": round(pairs / ms / 1e9, 3), "peak": round(valu_peak, 2),
-                "frac": round(pairs / ms / 1e9 / valu_peak, 4), "avg_ms": round(ms, 4), "traffic": None,
+                "frac": round(pairs / ms / 1e9 / valu_peak, 4), "avg_ms": round(ms, 4),
+                "traffic": traffic("knn_wave_kernel", "knn_kernel<1>", "knn_grid_kernel"),
                 "work": "%d brute-force-equivalent pair distances per batch of %d crops (the searches against pixel grids visit a window, not all pairs); peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 9 vector ops per pair" % (pairs, B)})
     # (3) gather + max over K (random_sample, ffb6d.py:128-146): the largest call of the step, pixel -> point at 128 x 128
     C, n_src, m, K = 64, 128 * 128, N // 4, 16
@@ -176,11 +211,11 @@ def kernel_rooflines(torch, dev, B, N):
     idx = torch.randint(0, n_src, (B, m, K), device=dev, dtype=torch.int32)
     for _ in range(3):
         ops.gather_max(feat, idx)
-    ms = timed(lambda: ops.gather_max(feat, idx), n, torch)
+    ms = timed_launches(lambda: ops.gather_max(feat, idx), n, torch)
     by = 4.0 * B * (C * n_src + K * m + C * m)
     out.append({"kernel": "gather_max_kernel<16> C=64, 16384 px -> %d points" % m, "bound": "hbm", "unit": "GB/s",
                 "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "avg_ms": round(ms, 4), "traffic": None, "work": "4*C*n_src + 4*K*n' + 4*C*n' bytes per crop (SURVEY.md 8d)"})
+                "avg_ms": round(ms, 4), "traffic": traffic("gather_max_"), "work": "4*C*n_src + 4*K*n' + 4*C*n' bytes per crop (SURVEY.md 8d)"})
     # (4) the largest 1x1 mix: z = W_tap . x of up_1 (PSPUpsample 1024 -> 256 as a low-resolution GEMM, 9*256 output channels at 32 x 32)
     Cin, Cout = 1024, 2304
     xg = torch.randn(B, Cin, 32 * 32, device=dev)
@@ -192,11 +227,12 @@ def kernel_rooflines(torch, dev, B, N):
                                                        ops._stream()), "gemm")
     for _ in range(3):
         gemm()
-    ms = timed(gemm, n, torch)
+    ms = timed_launches(gemm, n, torch)
     fl = 2.0 * Cin * Cout * B * 32 * 32
     out.append({"kernel": "conv_mfma16_kernel 1x1 1024->2304 @32x32 (tap GEMM of up_1)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
-                "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4), "traffic": None,
+                "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
+                "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 8>"),
                 "work": "2*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * 32 * 32)})
     # (5) the last image stage at the sampled pixels (up_3 + final at `choose`): replaces a 64 -> 64 3x3 convolution and a 1x1 + log-softmax
     # over the whole 256^2 map (361 + 130 us) -- priced against reading the 128^2 source map once and writing the N sampled columns
@@ -208,7 +244,7 @@ def kernel_rooflines(torch, dev, B, N):
     fin = lambda: ops.upconv_final_points(xs, (128, 128), ch, wk, sc, sh, 2, 0.25, wf, bf, (256, 256))
     for _ in range(3):
         fin()
-    ms = timed(fin, n, torch)
+    ms = timed_launches(fin, n, torch)
     by = 4.0 * B * 64 * (128 * 128 + N)
     out.append({"kernel": "upconv_final_points_kernel: up_3 + final at the %d sampled pixels of 256^2" % N, "bound": "hbm", "unit": "GB/s",
                 "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -604,20 +640,9 @@ def main():
             # launched on: an event pair per launch adds ~20 us of marker handling to every sample (8 % of this kernel)
             n_launch = max(args.steps, 10) if rank == 0 else 0
             if n_launch:
-                a, b = ev(), ev()
-                a.record()
-                for _ in range(n_launch):
-                    ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim)
-                b.record()
-                torch.cuda.synchronize()
-                mat_ms = a.elapsed_time(b) / n_launch
-                a, b = ev(), ev()
-                a.record()
-                for _ in range(n_launch):
-                    ops.match_packed(srows, mrows, B, N, M, prec)
-                b.record()
-                torch.cuda.synchronize()
-                fused_ms = a.elapsed_time(b) / n_launch
+                launches_ms = lambda fn: timed_launches(fn, n_launch, torch)
+                mat_ms = launches_ms(lambda: ops.match_packed(srows, mrows, B, N, M, prec, return_sim=True, sim_out=sim))
+                fused_ms = launches_ms(lambda: ops.match_packed(srows, mrows, B, N, M, prec))
             del sim
         roofline_fused = {"kernel": "match_kernel<fused arg-max> (+ split merge), back-to-back launches as the one the step issues", "bound": "mfma",
                           "achieved": round(mfma_flops / (fused_ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
@@ -626,12 +651,12 @@ def main():
                           "avg_ms": round(fused_ms, 4), "traffic": None}
         # PMC traffic comes from separate rocprofv3 --pmc passes (profiles/match_traffic.json), valid for the headline shape only
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "match_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tfile) and (B, N, M, args.precision) == (16, 2048, 8192, "bf16x3"):
             try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("materialised_bytes_per_launch")
-                roofline_fused["traffic"] = tj.get("fused_kernel", {}).get("bytes_per_launch")
+                tj = json.load(open(tfile))["kernels"]
+                traffic = tj["match_pipe_sim_kernel"]["bytes_per_launch"]
+                roofline_fused["traffic"] = tj["match_pipe_kernel"]["bytes_per_launch"]
             except Exception:
                 traffic = None
         line["roofline"] = {"kernel": "match_kernel<materialised sim> (N x 8192 descriptor-distance kernel)", "bound": "hbm",

@@ -360,9 +360,8 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                                                                  // H*W % 256 == 0 -- reads its rows at wpk + b * wbstride); 0 = shared weights
                                                                  long wbstride = 0,
                                                                  // 1: the grid is (channel tiles, pixel tiles) -- consecutive workgroups share
-                                                                 // a pixel tile, so a layer with many channel tiles streams its activations
-                                                                 // once instead of once per round of channel tiles (PMC: 412 -> ~120 MB for
-                                                                 // the 1024 -> 2304 tap GEMM)
+                                                                 // a pixel tile (development switch: measured no faster and heavier on the
+                                                                 // fabric than pixel tiles fastest, see conv1x1_launch)
                                                                  int co_fastest = 0)
 {
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
@@ -836,9 +835,10 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     const unsigned ptiles = gdm_cdiv(ptot, CV_PIX);
     const bool narrow = (GDM_CONV_SHAPE == 16) && Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
     const unsigned ctiles = gdm_cdiv(Cout, narrow ? 64 : CV_CO);    // the last block's rows beyond Cout are zero weights, never stored
-    // many channel tiles: channel tile = the fast grid axis (see the kernel's co_fastest)
-    static const int co_env = getenv("GDM_CONV_CO_FASTEST") ? atoi(getenv("GDM_CONV_CO_FASTEST")) : -1;
-    const int co_fast = (GDM_CONV_SHAPE == 16) && (co_env >= 0 ? co_env : (int)(ctiles >= 8 && ptiles <= 65535));
+    // GDM_CONV_CO_FASTEST=1 (development): channel tile = the fast grid axis (the kernel's co_fastest).  Measured on the 1024 -> 2304
+    // tap GEMM: same time, MORE fabric traffic (PMC 903 MB vs 573 MB per launch: each XCD then streams every weight panel), so off
+    static const int co_env = getenv("GDM_CONV_CO_FASTEST") ? atoi(getenv("GDM_CONV_CO_FASTEST")) : 0;
+    const int co_fast = (GDM_CONV_SHAPE == 16) && co_env > 0 && ptiles <= 65535;
     const dim3 grid = co_fast ? dim3(ctiles, ptiles) : dim3(ptiles, ctiles);
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;

@@ -23,6 +23,7 @@ KERNELS = collections.OrderedDict([
                                                        B * 34 * 34 * 8 * 512.0 + 8 * 2304 * 512.0 + 4.0 * B * 2304 * 1024)),
     ("knn_wave_kernel", ("K = 16 searches of the pyramid (unorganised supports)", None)),
     ("knn_kernel<1>", ("K = 1 searches of the pyramid", None)),
+    ("knn_grid_kernel", ("K = 16 searches against organised supports (window search)", None)),
     ("gather_max_", ("gather + max over K, C=64, 16384 px -> 512 points", 4.0 * B * (64 * 16384 + 16 * 512 + 64 * 512))),
     ("stem_kernel", ("conv7x7/2 + BN + ReLU + max-pool, 256^2 -> 64 x 64^2", 4.0 * B * 3 * 65536 + 49152 + 4.0 * B * 64 * 4096 * 2)),
     ("lfa_stage_kernel<32>", ("LFA stage level 0 (n = 2048, D = 32)", None)),
