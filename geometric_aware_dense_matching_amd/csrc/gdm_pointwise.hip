@@ -266,6 +266,211 @@ __global__ __launch_bounds__(NW * 64) void pointwise_kernel(const PwArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same layer on v_mfma_f32_16x16x4_f32 (exact fp32 products: the f32-input MFMA is an fmaf chain, MI355X_MICROARCH.md), for the
+// layers the FMA kernel runs at one or two waves per SIMD: there the 16 FMAs + 2 LDS reads + address arithmetic per K row of a wave
+// are bound by vector-instruction ISSUE, while one MFMA retires 16 x 16 x 4 products per instruction and takes its operands straight
+// from global memory in fragment order -- no LDS staging, no barrier in the K loop:
+//   A fragment (x):  lane l = point p0 + 16 g + (l & 15), row k0 + (l >> 4)      one dword per lane, 4 rows x 64 B per instruction
+//   B fragment (W):  lane l = channel c0 + (l & 15),      row k0 + (l >> 4)      one dword per lane (wt is [K][Cout])
+//   accumulator g:   lane l = channel c0 + (l & 15), points p0 + 16 g + 4 (l >> 4) + 0..3   = one 16-byte store channel-major
+// A workgroup = KS waves = the KS parts of the K axis of ONE tile of 64 points x 16 channels; partial sums are added through LDS in
+// fixed order.  Each wave walks its K range segment by segment (pointer increments only), four K rows per MFMA step.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float pw_f32x4;
+
+// VEC (no indexed segment, n % 4 == 0, 16-byte aligned operands): accumulator block g owns the points p0 + 4 (l & 15) + g instead of
+// p0 + 16 g + (l & 15), so ONE 16-byte load per lane fetches a K row's values for all four blocks (a wave-wide dword load costs the
+// texture path what a dwordx4 one does: 2 load instructions per step instead of 5), and the four blocks' results for one (row group,
+// r) are four consecutive points = one 16-byte store
+template <int KS, bool VEC>
+__global__ __launch_bounds__(KS * 64) void pointwise_mfma_kernel(const PwArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? KS : 1][16][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const long p0 = (long)blockIdx.x * PT;
+    const int c0 = (int)blockIdx.y * 16;
+    const int n = a.n, Cout = a.Cout, K = a.K;
+    const int kpart = (((K + KS - 1) / KS + 3) / 4) * 4;
+    const int kbeg = wave * kpart, kend = min(K, kbeg + kpart);
+
+    // this lane's four points (one per accumulator block)
+    long pb[4];
+    int pi[4];
+    long pg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // out-of-range points are clamped to valid ones (their results are never stored); VEC lanes load four consecutive points, so
+        // the clamp keeps the whole group inside the array (total % 4 == 0 there)
+        const long p = VEC ? min(p0 + 4 * l16, a.total - 4) + g : min(p0 + 16 * g + l16, a.total - 1);
+        pg[g] = p;
+        pb[g] = p / n;
+        pi[g] = (int)(p - pb[g] * n);
+    }
+    const int wcol = min(c0 + l16, Cout - 1);
+
+    pw_f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
+
+    int seg_start = 0;
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+        if (s >= a.nseg) break;
+        const float* sx = a.seg[s].x;
+        const int32_t* sidx = a.seg[s].idx;
+        const int sC = a.seg[s].C, sn = a.seg[s].n_src;
+        const int seg_end = seg_start + sC;
+        const int k0 = max(kbeg, seg_start), k1 = min(kend, seg_end);       // this wave's rows inside this segment
+        if (k0 < k1) {
+            const float* xp[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int col = pi[g];
+                if (sidx) col = min(max(sidx[pg[g]], 0), sn - 1);
+                xp[g] = sx + (pb[g] * sC + (k0 - seg_start + kq)) * (long)sn + col;
+            }
+            const float* wp = a.wt + (long)(k0 + kq) * Cout + wcol;
+            const long xinc = 4L * sn, winc = 4L * Cout;
+            const int nfull = (k1 - k0) / 4;                               // steps whose four rows all lie inside [k0, k1)
+            // software pipeline in groups of four steps: group i + 1's 20 loads are issued BEFORE group i's 16 MFMAs (two register
+            // sets, the loop unrolled by two so that both are statically indexed)
+            const int ngrp = nfull / 4;
+            float xa[4][4], wa[4], xb[4][4], wb[4];
+            auto load_grp = [&](float (&xv)[4][4], float (&wv)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wv[u] = wp[0];
+                    wp += winc;
+                    if (VEC) {
+                        const float4 t = *reinterpret_cast<const float4*>(xp[0]);
+                        xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                        xp[0] += xinc;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            xv[u][g] = xp[g][0];
+                            xp[g] += xinc;
+                        }
+                    }
+                }
+            };
+            auto mfma_grp = [&](const float (&xv)[4][4], const float (&wv)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][g], wv[u], acc[g], 0, 0, 0);
+            };
+            int st = 4 * ngrp;
+            if (ngrp > 0) {
+                load_grp(xa, wa);
+                int gi = 0;
+                for (; gi + 2 < ngrp; gi += 2) {
+                    load_grp(xb, wb);
+                    mfma_grp(xa, wa);
+                    load_grp(xa, wa);
+                    mfma_grp(xb, wb);
+                }
+                if (gi + 1 < ngrp) {                                        // two groups left: a in flight, then b
+                    load_grp(xb, wb);
+                    mfma_grp(xa, wa);
+                    mfma_grp(xb, wb);
+                } else {
+                    mfma_grp(xa, wa);
+                }
+            }
+            for (; st < nfull; ++st) {
+                const float wv = wp[0];
+                wp += winc;
+                float xv[4];
+                if (VEC) {
+                    const float4 t = *reinterpret_cast<const float4*>(xp[0]);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                    xp[0] += xinc;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        xv[g] = xp[g][0];
+                        xp[g] += xinc;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[g], wv, acc[g], 0, 0, 0);
+            }
+            if (k0 + 4 * nfull < k1) {                                      // the last, partial step: rows past k1 contribute zero
+                const bool in = k0 + 4 * nfull + kq < k1;
+                const long back = in ? 0 : (long)(k0 + 4 * nfull + kq - (k1 - 1));      // out-of-range lanes re-read row k1 - 1
+                const float wraw = wp[-back * Cout];
+                const float wv = in ? wraw : 0.f;
+                float xraw[4];
+                if (VEC) {
+                    const float4 t = *reinterpret_cast<const float4*>(xp[0] - back * sn);
+                    xraw[0] = t.x; xraw[1] = t.y; xraw[2] = t.z; xraw[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xraw[g] = xp[g][-back * sn];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? xraw[g] : 0.f, wv, acc[g], 0, 0, 0);
+            }
+        }
+        seg_start = seg_end;
+    }
+
+    if (KS > 1) {
+        if (wave != 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < KS; ++w)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] += red[w][g * 4 + r][lane];
+    }
+
+    const int co = c0 + l16;
+    if (co >= Cout) return;
+    const float sc = a.scale ? a.scale[co] : 1.f, sh = a.shift ? a.shift[co] : 0.f;
+    auto finish = [&](float y) {
+        y = fmaf(y, sc, sh);
+        if (a.act == 1) y = fmaxf(y, 0.f);
+        else if (a.act == 2) y = y > 0.f ? y : y * a.slope;
+        return y;
+    };
+    // four consecutive points per (j, i): VEC -- block g = point 4 (4 kq + r) + g, so (j, i) = (r, g); else -- point 16 g + 4 kq + r, (j, i) = (g, r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = finish(VEC ? acc[i][j] : acc[j][i]);
+        const long q0 = p0 + (VEC ? 16 * kq + 4 * j : 16 * j + 4 * kq);   // first of the four consecutive points
+        if (a.point_major) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (q0 + r < a.total) a.out[(q0 + r) * a.outC + a.out_c0 + co] = v[r];
+        } else if (n % 4 == 0 && q0 + 3 < a.total) {                       // four points of one crop, 16-byte aligned
+            const long b = q0 / n;
+            *reinterpret_cast<float4*>(a.out + (b * a.outC + a.out_c0 + co) * n + (q0 - b * n)) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long q = q0 + r;
+                if (q >= a.total) break;
+                const long b = q / n;
+                a.out[(b * a.outC + a.out_c0 + co) * n + (q - b * n)] = v[r];
+            }
+        }
+    }
+}
+
 bool seg_ok(const gdm_pw_seg& s, int n)
 {
     return s.x && s.C >= 1 && s.n_src >= 1 && (s.idx || s.n_src == n);
@@ -323,6 +528,26 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
         if (vec) hipLaunchKernelGGL((pointwise_kernel<NW, KS, true>), grid, dim3(NW * 64), 0, st, a);                               \
         else hipLaunchKernelGGL((pointwise_kernel<NW, KS, false>), grid, dim3(NW * 64), 0, st, a);                                  \
     } while (0)
+    static const int mfma_env = getenv("GDM_PW_MFMA") ? atoi(getenv("GDM_PW_MFMA")) : 1;
+    if (mfma_env && a.K >= 32 && gdm_cdiv(Cout, 16) <= 65535) {
+        // K parts per tile: as many as leave each wave >= 16 rows, at most 8 (= waves of the workgroup)
+        int ks = 1;
+        while (ks < 8 && a.K / (2 * ks) >= 16 && tiles * gdm_cdiv(Cout, 16) * ks < 4096) ks *= 2;
+        const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, 16));
+        bool mvec = (n % 4 == 0) && !getenv("GDM_PW_NOVEC");
+        for (int sgi = 0; sgi < nseg; ++sgi) mvec = mvec && !segs[sgi].idx && (((uintptr_t)segs[sgi].x & 15) == 0) && segs[sgi].n_src % 4 == 0;
+#define GDM_PWM(KSV)                                                                                                    \
+        do {                                                                                                             \
+            if (mvec) hipLaunchKernelGGL((pointwise_mfma_kernel<KSV, true>), grid, dim3(KSV * 64), 0, st, a);            \
+            else hipLaunchKernelGGL((pointwise_mfma_kernel<KSV, false>), grid, dim3(KSV * 64), 0, st, a);                \
+        } while (0)
+        if (ks == 1) GDM_PWM(1);
+        else if (ks == 2) GDM_PWM(2);
+        else if (ks == 4) GDM_PWM(4);
+        else GDM_PWM(8);
+#undef GDM_PWM
+        return gdm_launch_status("pointwise_mfma_kernel");
+    }
     if (base >= 256 || a.K < 64) GDM_PW_LAUNCH(4, 1, 64);
     else if (a.K >= 256 && gdm_cdiv(Cout, 16) <= 65535) GDM_PW_LAUNCH(8, 8, 16);
     else GDM_PW_LAUNCH(8, 2, 64);

@@ -686,6 +686,8 @@ def test_affine_relu_maxpool_equals_modules(ops, B, C, H, W):
     (2, 512, (64, 128), 64, 128, False),              # decoder over cat(skip, nearest_interpolation(deeper))
     (3, 37, (5, 3, 6), 7, 11, False),                 # ragged everything, three segments
     (1, 50, (70,), 3, None, False),                   # ragged K with the split (few points)
+    (2, 36, (512,), 1024, None, False),               # PSP prior at 6 x 6: n % 4 == 0 with a PARTIAL last tile (72 points): the
+    (1, 4, (64, 64), 48, None, False),                #   16-byte operand loads of the out-of-range lanes must stay inside the array
     (4, 512, (64,), 64, None, True),                  # point-major product for the 64-channel fusion kernel
     (2, 130, (70,), 130, None, True),
 ])
