@@ -140,8 +140,14 @@ def test_headline_full_path_vs_oracle_with_mesh_branch(headline_model, c2_run):
     mesh_got = ep["mesh"][0].cpu()
     assert mesh_got.shape == (128, M2)
     assert (mesh_got - mesh_want).abs().max() < 2e-4 * max(1.0, mesh_want.abs().max().item())
-    assert torch.allclose(ep["rgbd"].cpu(), want["rgbd"], rtol=1e-3, atol=5e-3)
-    assert torch.allclose(ep["seg"].cpu(), want["seg"], rtol=1e-3, atol=5e-3)
+    if os.environ.get("GDM_TEST_REPORT"):
+        for k in ("rgbd", "seg"):
+            d = (ep[k].cpu() - want[k]).abs()
+            print("REPORT full_path %s: max|diff| %.3e, max|want| %.3e, max rel-to-scale %.3e" % (k, d.max().item(), want[k].abs().max().item(),
+                                                                                              d.max().item() / want[k].abs().max().item()))
+    # measured (round 3): max |diff| 8.4e-5 on rgbd (values up to 5.5), 5.4e-5 on seg -- split-bf16 products through ~25 layers
+    assert torch.allclose(ep["rgbd"].cpu(), want["rgbd"], rtol=1e-4, atol=5e-4)
+    assert torch.allclose(ep["seg"].cpu(), want["seg"], rtol=1e-4, atol=5e-4)
     for b in range(2):                                                                    # matching of the product's own descriptors
         wv, wi, ws = ops_ref.match_argmax(ep["rgbd"][b].cpu(), mesh_got)
         assert (res["best_sim"][b].cpu() - wv).abs().max() < 1e-4
@@ -152,8 +158,9 @@ def test_headline_full_path_vs_oracle_with_mesh_branch(headline_model, c2_run):
 
 def test_headline_batch16_rows_equal_batch2_rows(headline_model, c2_run):
     """The bench's launch shapes (B=16: level-0 LFA at n=2048, B=16 conv / up-conv / matching launches): crops 0 and 1 of a
-    batch of 16 give the results they give in a batch of 2 (crops are independent; MIOpen may pick another algorithm per batch
-    size, hence 1e-4 relative instead of bit equality; indices exact)."""
+    batch of 16 give the results they give in a batch of 2.  Crops are independent and no library kernel is left in the step; the one
+    batch-dependent piece of arithmetic is the K split of the per-point 1x1 layers (the number of partial sums is chosen from the
+    grid size), hence 5e-5 of the output scale instead of bit equality; neighbour indices exact, arg-max equal up to near-ties."""
     from geometric_aware_dense_matching_amd import matching
     model, _ = headline_model
     _, d2, ep2, _, res2 = c2_run
@@ -166,11 +173,16 @@ def test_headline_batch16_rows_equal_batch2_rows(headline_model, c2_run):
         res = matching.match_frames(ep)
     assert torch.isfinite(ep["rgbd"]).all() and torch.isfinite(ep["seg"]).all()
     scale = ep2["rgbd"].abs().max().item()
-    assert (ep["rgbd"][:2] - ep2["rgbd"]).abs().max().item() < 1e-4 * scale
+    if os.environ.get("GDM_TEST_REPORT"):
+        print("REPORT b16_vs_b2 rgbd max|diff| %.3e scale %.3e seg %.3e sim %.3e idx_equal %.6f" % (
+            (ep["rgbd"][:2] - ep2["rgbd"]).abs().max().item(), scale, (ep["seg"][:2] - ep2["seg"]).abs().max().item(),
+            (res["best_sim"][:2] - res2["best_sim"]).abs().max().item(), (res["best_idx"][:2] == res2["best_idx"]).float().mean().item()))
+    # measured (round 3): 7.3e-5 on rgbd (1.3e-5 of its scale), 5.2e-5 on seg, 2.3e-6 on the maxima, every arg-max index equal
+    assert (ep["rgbd"][:2] - ep2["rgbd"]).abs().max().item() < 5e-5 * scale
     assert (ep["seg"][:2] - ep2["seg"]).abs().max().item() < 1e-4 * max(1.0, ep2["seg"].abs().max().item())
     assert torch.equal(ep["mesh"], ep2["mesh"])
-    assert (res["best_sim"][:2] - res2["best_sim"]).abs().max().item() < 1e-4
-    assert (res["best_idx"][:2] == res2["best_idx"]).float().mean().item() > 0.995
+    assert (res["best_sim"][:2] - res2["best_sim"]).abs().max().item() < 1e-5
+    assert (res["best_idx"][:2] == res2["best_idx"]).float().mean().item() > 0.9995
     # crops 2..15: against the oracle's matching on the product's descriptors (sampled crops)
     from oracle import ops_ref
     for b in (7, 15):
