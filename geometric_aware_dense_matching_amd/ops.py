@@ -129,29 +129,41 @@ def knn_jobs(jobs, B, keep_workspace=None):
     columns / rows that can hold a neighbour (same results).  One launch per K class.  Returns the idx tensors i32[B,Q,K]."""
     n = len(jobs)
     arr = (KnnJob * n)()
-    outs = []
-    keep = []
-    for i, job in enumerate(jobs):
+    # ONE allocation for all index arrays (22 per pyramid): the host time of this function sits on the step's critical path (the
+    # searches are its first kernels), and 22 allocator calls were a third of it
+    sizes = []
+    for job in jobs:
         sup, qry, K = job[:3]
-        grid_w = int(job[3]) if len(job) > 3 else 0
         for t, nm in ((sup, "support"), (qry, "query")):
             if not t.is_cuda or t.dtype != torch.float32:
                 raise RuntimeError("knn_jobs: %s must be a CUDA float32 tensor" % nm)
             if t.dim() != 3 or t.shape[0] != B or t.shape[2] != 3 or t.stride(2) != 1 or t.stride(1) != 3:
                 raise ValueError("knn_jobs: %s must be [B,n,3] with unit point stride, got %s strides %s" %
                                  (nm, tuple(t.shape), t.stride()))
+        sizes.append(B * qry.shape[1] * K)
+    starts = []
+    tot = 0
+    for sz in sizes:                                          # every array starts on a 256-byte boundary (its readers use 16-byte loads)
+        starts.append(tot)
+        tot += (sz + 63) // 64 * 64
+    slab = torch.empty(tot, dtype=torch.int32, device=jobs[0][0].device)
+    base = slab.data_ptr()
+    outs = []
+    for i, job in enumerate(jobs):
+        off = starts[i]
+        sup, qry, K = job[:3]
+        grid_w = int(job[3]) if len(job) > 3 else 0
         S, Q = sup.shape[1], qry.shape[1]
-        out = torch.empty((B, Q, K), dtype=torch.int32, device=sup.device)
-        arr[i].support = sup.data_ptr()
-        arr[i].query = qry.data_ptr()
-        arr[i].idx = out.data_ptr()
-        arr[i].d2 = None
-        arr[i].support_bstride = sup.stride(0) if B > 1 else S * 3
-        arr[i].query_bstride = qry.stride(0) if B > 1 else Q * 3
-        arr[i].S, arr[i].Q, arr[i].K = S, Q, K
-        arr[i].grid_w = grid_w if (grid_w > 0 and S % grid_w == 0) else 0
-        outs.append(out)
-        keep.append((sup, qry))
+        a = arr[i]
+        a.support = sup.data_ptr()
+        a.query = qry.data_ptr()
+        a.idx = base + 4 * off
+        a.d2 = None
+        a.support_bstride = sup.stride(0) if B > 1 else S * 3
+        a.query_bstride = qry.stride(0) if B > 1 else Q * 3
+        a.S, a.Q, a.K = S, Q, K
+        a.grid_w = grid_w if (grid_w > 0 and S % grid_w == 0) else 0
+        outs.append(slab[off:off + sizes[i]].view(B, Q, K))
     ws = _knn_launch(arr, n, B, jobs[0][0].device)
     if keep_workspace is not None:
         keep_workspace.append(ws)        # the caller keeps it alive as long as the results (explicit lifetime across streams)
