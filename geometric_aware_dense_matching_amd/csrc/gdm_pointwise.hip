@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int PT = 64, XS = 68;       // XS: padded row of the x tile (keeps float4 reads aligned, spreads banks)
-constexpr int MAXSEG = 3;
+constexpr int MAXSEG = 4;              // the MFMA form walks up to four segments, the FMA form three
 
 struct PwSegDev {
     const float* x;
@@ -548,6 +548,7 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
 #undef GDM_PWM
         return gdm_launch_status("pointwise_mfma_kernel");
     }
+    GDM_CHECK_ARG(nseg <= 3, "gdm_pointwise_hip: four segments need K >= 32 (the MFMA form)");
     if (base >= 256 || a.K < 64) GDM_PW_LAUNCH(4, 1, 64);
     else if (a.K >= 256 && gdm_cdiv(Cout, 16) <= 65535) GDM_PW_LAUNCH(8, 8, 16);
     else GDM_PW_LAUNCH(8, 2, 64);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(128) void spline_direct_vec_kernel(const float* __r
                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                                 const float* __restrict__ attr, const float* __restrict__ root_t,
                                                                 const float* __restrict__ bias, int M, int Cin, int C, int KS,
-                                                                float* __restrict__ out)
+                                                                float* __restrict__ out, float* __restrict__ out_t)
 {
     const int tpv = C / 4;                                        // threads per vertex
     const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
@@ -246,7 +246,11 @@ __global__ __launch_bounds__(128) void spline_direct_vec_kernel(const float* __r
         r.x += bv.x; r.y += bv.y; r.z += bv.z; r.w += bv.w;
     }
     if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-    *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+    if (out) *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+    if (out_t) {                                                  // channel-major copy [C, M]: what the next layer's GEMM and 1x1 layers read
+        out_t[(long)(o + 0) * M + i] = r.x; out_t[(long)(o + 1) * M + i] = r.y;
+        out_t[(long)(o + 2) * M + i] = r.z; out_t[(long)(o + 3) * M + i] = r.w;
+    }
 }
 
 // Aggregation for the edge-grouped form: Y f32[R,128-wide rows of C] holds x_j . W[wi] for every (source, kernel index) pair that
@@ -281,7 +285,7 @@ template <bool RELU>
 __global__ __launch_bounds__(128) void spline_pairs_aggregate_vec_kernel(const float* __restrict__ Y, const int32_t* __restrict__ rowptr,
                                                                          const int32_t* __restrict__ pos, const float* __restrict__ basis,
                                                                          const float* __restrict__ root, const float* __restrict__ bias,
-                                                                         int M, int C, float* __restrict__ out)
+                                                                         int M, int C, float* __restrict__ out, float* __restrict__ out_t)
 {
     const int tpv = C / 4;
     const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
@@ -311,25 +315,31 @@ __global__ __launch_bounds__(128) void spline_pairs_aggregate_vec_kernel(const f
         r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
     }
     if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-    *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+    if (out) *reinterpret_cast<float4*>(out + (long)i * C + o) = r;
+    if (out_t) {
+        out_t[(long)(o + 0) * M + i] = r.x; out_t[(long)(o + 1) * M + i] = r.y;
+        out_t[(long)(o + 2) * M + i] = r.z; out_t[(long)(o + 3) * M + i] = r.w;
+    }
 }
 
 } // namespace
 
-extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
-                                              const float* root, const float* bias, int M, int C, int relu, float* out, void* stream)
+extern "C" int gdm_spline_pairs_aggregate2_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                               const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t,
+                                               void* stream)
 {
-    GDM_CHECK_ARG(Y && rowptr && pos && basis && out, "gdm_spline_pairs_aggregate_hip: NULL pointer");
+    GDM_CHECK_ARG(Y && rowptr && pos && basis && (out || out_t), "gdm_spline_pairs_aggregate_hip: NULL pointer");
     GDM_CHECK_ARG(M >= 1 && C >= 1, "gdm_spline_pairs_aggregate_hip: bad shape");
     if (C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!root || ((uintptr_t)root & 15) == 0) &&
         (!bias || ((uintptr_t)bias & 15) == 0)) {
         const dim3 grid(gdm_cdiv(M, 128 / (C / 4)));
         if (relu)
-            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out);
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t);
         else
-            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out);
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t);
         return gdm_launch_status("spline_pairs_aggregate_vec_kernel");
     }
+    GDM_CHECK_ARG(out && !out_t, "gdm_spline_pairs_aggregate2_hip: the channel-major output needs C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
     if (relu)
         hipLaunchKernelGGL(spline_pairs_aggregate_kernel<true>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
     else
@@ -337,11 +347,28 @@ extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* row
     return gdm_launch_status("spline_pairs_aggregate_kernel");
 }
 
+extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                              const float* root, const float* bias, int M, int C, int relu, float* out, void* stream)
+{
+    return gdm_spline_pairs_aggregate2_hip(Y, rowptr, pos, basis, root, bias, M, C, relu, out, nullptr, stream);
+}
+
+extern "C" int gdm_spline_direct2_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                     const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                                     float* out, float* out_t, void* stream);
+
 extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
                                      const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
                                      float* out, void* stream)
 {
-    GDM_CHECK_ARG(x && weight && rowptr && src && attr && out, "gdm_spline_direct_hip: NULL pointer");
+    return gdm_spline_direct2_hip(x, weight, rowptr, src, attr, root_t, bias, M, Cin, C, kernel_size, relu, out, nullptr, stream);
+}
+
+extern "C" int gdm_spline_direct2_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                     const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                                     float* out, float* out_t, void* stream)
+{
+    GDM_CHECK_ARG(x && weight && rowptr && src && attr && (out || out_t), "gdm_spline_direct_hip: NULL pointer");
     GDM_CHECK_ARG(M >= 1 && C >= 1 && kernel_size >= 2 && Cin >= 1 && Cin <= 16, "gdm_spline_direct_hip: bad shape M=%d Cin=%d (<= 16) C=%d ks=%d", M, Cin, C, kernel_size);
     const bool vec = C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)weight & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                      (!root_t || ((uintptr_t)root_t & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
@@ -350,12 +377,13 @@ extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const 
         const dim3 grid(gdm_cdiv(M, vpb));
         if (relu)
             hipLaunchKernelGGL((spline_direct_vec_kernel<true, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
-                               bias, M, Cin, C, kernel_size, out);
+                               bias, M, Cin, C, kernel_size, out, out_t);
         else
             hipLaunchKernelGGL((spline_direct_vec_kernel<false, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
-                               bias, M, Cin, C, kernel_size, out);
+                               bias, M, Cin, C, kernel_size, out, out_t);
         return gdm_launch_status("spline_direct_vec_kernel");
     }
+    GDM_CHECK_ARG(out && !out_t, "gdm_spline_direct2_hip: the channel-major output needs C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
     if (relu)
         hipLaunchKernelGGL((spline_direct_kernel<true, 16>), dim3(M), dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t, bias, Cin, C, kernel_size, out);
     else

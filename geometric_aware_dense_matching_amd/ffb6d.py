@@ -175,7 +175,9 @@ class FFB6DEmb(nn.Module):
         p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)
         return fuse_layer(torch.cat((rgb_emb0, p2r_emb), dim=1))
 
-    def forward(self, inputs, end_points=None):
+    def forward(self, inputs, end_points=None, parts=False):
+        """-> f32[B,128,N] (ffb6d.py:285: cat of the 64 image channels at the chosen pixels and the 64 point channels); parts=True
+        returns the two halves un-concatenated, for a consumer that reads them in place (the fused per-point heads)."""
         if fused_eval(inputs["rgb"], self):
             pre = self.cnn_pre_stages                                         # conv1, bn1, relu, maxpool
             s0, b0 = folded_bn(pre[1])
@@ -266,6 +268,8 @@ class FFB6DEmb(nn.Module):
             rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
             bs, di, _, _ = rgb_emb.size()
             rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+        if parts:
+            return rgb_emb_c, p_emb
         return torch.cat([rgb_emb_c, p_emb], dim=1)
 
     def _sparse_final_ok(self, rgb):

@@ -180,19 +180,22 @@ class GeoMatch(nn.Module):
         if not end_points:
             end_points = {}
         rgb = inputs["rgb"]
+        heads = self._fused_heads(rgb)
+        # the fused heads read the two halves of the embedding in place: no concat launch
+        emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
         if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
             # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
             with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
                 mesh_features = self.mesh_features()
-            rgbd_emb = self.pcd_emb(inputs)
+            rgbd_emb = emb(inputs)
             f.join(mesh_features)
         else:
-            rgbd_emb = self.pcd_emb(inputs)
+            rgbd_emb = emb(inputs)
             mesh_features = self.mesh_features()
-        heads = self._fused_heads(rgb)
         if heads is not None:
             # feature_encoding_layer, normalize_feature_layer, the residual add and seg_layer: nine per-point 1x1 convolutions, one launch
-            rgbd_features, seg_features = ops.point_heads(rgbd_emb, None, heads[0], heads[1], feat_layer=3, res_layer=4)
+            a, b = rgbd_emb if isinstance(rgbd_emb, tuple) else (rgbd_emb, None)
+            rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
         else:
             rgbd_features = self.feature_encoding_layer(rgbd_emb)
             rgbd_normalized = self.normalize_feature_layer(rgbd_features)

@@ -78,6 +78,39 @@ class SplineConv(nn.Module):
             state_dict[prefix + "lin.weight"] = state_dict.pop(old).t().contiguous()
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def _root_t(self):
+        w = self.lin.weight
+        key = (w._version, w.data_ptr())
+        cache = self.__dict__.get("_gdm_root_t")
+        if cache is None or cache[0] != key:
+            cache = (key, w.detach().t().contiguous())
+            self.__dict__["_gdm_root_t"] = cache
+        return cache[1]
+
+    def forward_direct_cm(self, x, rowptr, src, attr, relu):
+        """First layer (cin <= 16), result CHANNEL-major f32[1, cout, M]: what the next layer's grouped GEMM / root product and the
+        final linear read in place (no transposing copy)."""
+        M = x.shape[0]
+        out_t = torch.empty((1, self.cout, M), dtype=torch.float32, device=x.device)
+        xc = x.contiguous()
+        check(_lib.lib().gdm_spline_direct2_hip(xc.data_ptr(), self.weight.data_ptr(), rowptr.data_ptr(), src.data_ptr(), attr.data_ptr(),
+                                                self._root_t().data_ptr(), self.bias.data_ptr(), M, self.cin, self.cout, KERNEL_SIZE, int(relu),
+                                                None, out_t.data_ptr(), ops._stream()), "gdm_spline_direct2_hip")
+        return out_t
+
+    def forward_grouped_cm(self, xt, rowptr, pairs, relu):
+        """128 -> 128 layer on the edge-grouped GEMM, channel-major in (xt f32[1, cin, M]) and out (f32[1, cout, M])."""
+        M = xt.shape[2]
+        nk = KERNEL_SIZE ** 3
+        wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin), (self.weight,))
+        Y = ops.gemm_grouped(xt, wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout)
+        root = ops.pointwise([xt], self._root_t(), point_major=True)                       # [1, M, cout] = x @ W_root^T
+        out_t = torch.empty((1, self.cout, M), dtype=torch.float32, device=xt.device)
+        check(_lib.lib().gdm_spline_pairs_aggregate2_hip(Y.data_ptr(), rowptr.data_ptr(), pairs["pos"].data_ptr(), pairs["basis"].data_ptr(),
+                                                         root.data_ptr(), self.bias.data_ptr(), M, self.cout, int(relu), None,
+                                                         out_t.data_ptr(), ops._stream()), "gdm_spline_pairs_aggregate2_hip")
+        return out_t
+
     def forward(self, x, rowptr, src, attr, relu=False, pairs=None):
         M = x.shape[0]
         nk = KERNEL_SIZE ** 3
@@ -290,8 +323,40 @@ class SplineCNN_Mesh(nn.Module):
             self._pairs = build_spline_pairs(self._csr[1], self._csr[2], M, self.out_channels) if ei.is_cuda and self.out_channels == 128 else None
         return self._csr
 
+    def _channel_major_ok(self):
+        convs = list(self.mesh_convs)
+        return (settings.USE_POINTWISE and settings.USE_MFMA_GEMM and settings.USE_GROUPED_SPLINE and self.cat and self.mesh_final is not None
+                and (not self.training) and not torch.is_grad_enabled() and self.xyz.is_cuda and self._pairs is not None and len(convs) <= 3
+                and convs[0].cin <= 16 and convs[0].cout == 128 and all(c.cin % 128 == 0 and c.cout == 128 for c in convs[1:]))
+
+    def _forward_channel_major(self, rowptr, src, attr):
+        """Inference: every layer hands its result on channel-major ([1, C, M]), which is what the next layer's grouped GEMM and root
+        product read and what the final linear reads as concat-free segments -- no transposing copies, no torch.cat, no library GEMM;
+        the result f32[128, M] is the layout GeoMatch.forward returns."""
+        x0 = self.mesh_graph_x
+        key = (x0._version, x0.data_ptr())
+        cache = self.__dict__.get("_gdm_x0_t")
+        if cache is None or cache[0] != key:
+            cache = (key, x0.detach().t().contiguous().unsqueeze(0))       # [1, 9, M], constant per object
+            self.__dict__["_gdm_x0_t"] = cache
+        segs = [cache[1]]
+        convs = list(self.mesh_convs)
+        segs.append(convs[0].forward_direct_cm(x0, rowptr, src, attr, True))
+        for conv in convs[1:]:
+            segs.append(conv.forward_grouped_cm(segs[-1], rowptr, self._pairs, True))
+        w = self.mesh_final.weight
+        key = (w._version, w.data_ptr())
+        cache = self.mesh_final.__dict__.get("_gdm_wt")
+        if cache is None or cache[0] != key:
+            cache = (key, w.detach().t().contiguous())
+            self.mesh_final.__dict__["_gdm_wt"] = cache
+        out = ops.pointwise(segs, cache[1], None, self.mesh_final.bias)     # [1, 128, M]; eval: dropout is the identity
+        return out[0]
+
     def forward(self):
         rowptr, src, attr = self._ensure_graph()
+        if self._channel_major_ok():
+            return self._forward_channel_major(rowptr, src, attr)
         feats = [self.mesh_graph_x]
         for conv in self.mesh_convs:
             feats.append(conv(feats[-1], rowptr, src, attr, relu=True, pairs=self._pairs))   # F.relu(conv(...)) (SplineCNN.py:238-239)

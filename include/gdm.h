@@ -202,6 +202,14 @@ int gdm_gemm_grouped_hip(const void* xpk, const void* wpk, const int32_t* rowidx
                          int Cin, int Cout_total, float* out, void* stream);
 int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
                                    const float* root, const float* bias, int M, int C, int relu, float* out, void* stream);
+/* The two kernels above with an optional second output out_t f32[C, M] (channel-major: what the next layer's grouped GEMM, its root
+ * product and the final linear read as gdm_pointwise_hip segments), out and out_t may each be NULL but not both; out_t needs
+ * C % 4 == 0 and 512 % C == 0. */
+int gdm_spline_direct2_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                           const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                           float* out, float* out_t, void* stream);
+int gdm_spline_pairs_aggregate2_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                    const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).
@@ -455,7 +463,7 @@ int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, in
  * fusion layers over cat(point, pooled pixel) features (ffb6d.py:224-231,259-265) and the decoder layers over
  * cat(skip, nearest_interpolation(deeper)) (ffb6d.py:246-250,268-272; the interpolation = `idx` of the second segment).
  *   out[b, out_c0 + c, i] = act( scale[c] * sum_k wt[k][c] * X[b,k,i] + shift[c] )
- * X = the channels of segs[0], segs[1], segs[2] in order (the concat, never formed; nseg in [1,3]).  A segment is f32[B,C,n_src]
+ * X = the channels of segs[0], segs[1], ... in order (the concat, never formed; nseg in [1,4], four only when K >= 32).  A segment is f32[B,C,n_src]
  * channel-major, read at column i (n_src == n) or at idx[b*n + i] (i32, any n_src).  A residual branch
  * s1*(W1 . x1) + b1 + s2*(W2 . x2) + b2 is the two-segment layer with wt = [s1*W1^T ; s2*W2^T], shift = b1 + b2 (the caller folds).
  * wt f32[K,Cout] TRANSPOSED weight, K = sum of the segments' C; scale / shift f32[Cout] or NULL (1 / 0).
