@@ -90,6 +90,34 @@ __global__ __launch_bounds__(256) void wgrad_pack_go_kernel(const float* __restr
     *reinterpret_cast<uint4*>(r + 256 + g * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
+// The 1x1 case (a plain product over pixels, dW[co,ci] = sum_{b,p} go[b,co,p] * x[b,ci,p]): no tap, no halo.  x f32[B,Cin,P], P % 128 == 0
+// -> the GEMM's "activations" on a 1 x Cin grid: chunk c, plane q (hi) / 16 + q (lo), element (1, ci + 1) of a 3 x (Cin + 2) grid.
+// One block: one chunk x 64 input channels; lanes = channels on the store side, = pixels on the load side (through LDS).
+__global__ __launch_bounds__(256) void wgrad_pack_x1_kernel(const float* __restrict__ x, int Cin, int P, unsigned char* __restrict__ out)
+{
+    __shared__ float t[64][129];
+    const int tid = threadIdx.x;
+    const int cpi = P / 128;
+    const int c = blockIdx.x, b = c / cpi, cl = c - b * cpi;
+    const int ci0 = blockIdx.y * 64;
+    for (int e = tid; e < 64 * 128; e += 256) {
+        const int p = e & 127, ci = e >> 7;
+        t[ci][p] = (ci0 + ci < Cin) ? x[((long)b * Cin + ci0 + ci) * P + cl * 128 + p] : 0.f;
+    }
+    __syncthreads();
+    const long plane = (long)3 * (Cin + 2);
+    for (int item = tid; item < 16 * 64; item += 256) {
+        const int ci = item & 63, q = item >> 6;
+        if (ci0 + ci >= Cin) continue;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gdm_split2(t[ci][8 * q + 2 * j], t[ci][8 * q + 2 * j + 1], hi[j], lo[j]);
+        unsigned char* o = out + ((((long)c * 32 + q) * plane) + (Cin + 2) + ci0 + ci + 1) * 16;
+        *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + 16 * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 bool shape_ok(int B, int C, int H, int W)
 {
     return B >= 1 && C >= 1 && H >= 1 && (W == 32 || W == 64) && (H * W) % 128 == 0;
@@ -131,4 +159,20 @@ extern "C" int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, in
     hipLaunchKernelGGL(wgrad_pack_go_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, go, Cout, CoutP,
                        H * W, rows, (unsigned char*)out);
     return gdm_launch_status("wgrad_pack_go_kernel");
+}
+
+extern "C" size_t gdm_wgrad_x1_bytes(int B, int Cin, int P)
+{
+    if (B < 1 || Cin < 1 || P < 128 || P % 128 != 0 || Cin % 32 != 0) return 0;
+    return (size_t)B * (P / 128) * 32 * 3 * (Cin + 2) * 16;
+}
+
+extern "C" int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void* out, void* stream)
+{
+    GDM_CHECK_ARG(x && out, "gdm_wgrad_pack_x1_hip: NULL pointer");
+    GDM_CHECK_ARG(gdm_wgrad_x1_bytes(B, Cin, P) != 0, "gdm_wgrad_pack_x1_hip: unsupported shape B=%d Cin=%d P=%d (P %% 128 == 0, Cin %% 32 == 0)", B, Cin, P);
+    GDM_CHECK_ARG(((uintptr_t)out & 15) == 0, "gdm_wgrad_pack_x1_hip: out must be 16-byte aligned");
+    dim3 grid(B * (P / 128), gdm_cdiv(Cin, 64));
+    hipLaunchKernelGGL(wgrad_pack_x1_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, P, (unsigned char*)out);
+    return gdm_launch_status("wgrad_pack_x1_kernel");
 }

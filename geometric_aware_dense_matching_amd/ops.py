@@ -812,7 +812,88 @@ def wx(w2d, x3):
     """W f32[Cout,Cin] . x f32[B,Cin,n] -> f32[B,Cout,n] as ONE batched GEMM on the shared weight.  torch.matmul(2-D, 3-D) folds the
     batch into GEMM rows instead and pays a transposing copy of the product (and of its gradient) to get back to [B,Cout,n]:
     2 ms of an 83 ms training step on the 9*Cout-channel tap tensors of PSPUpsample."""
+    if torch.is_grad_enabled() and (w2d.requires_grad or x3.requires_grad) and x3.is_cuda and x3.dtype == torch.float32:
+        return _WxTrain.apply(x3.contiguous(), w2d.contiguous())
     return torch.bmm(w2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+
+
+def _wgrad_parts(nchunk, tiles):
+    """K split of a pixel-contraction GEMM: the largest divisor of the chunk count that keeps the launch near one round of
+    workgroups (a part has `tiles` of them) and at least four chunks per part."""
+    parts = 1
+    for d in range(1, nchunk + 1):
+        if nchunk % d == 0 and d * tiles <= 320 and nchunk // d >= 4:
+            parts = d
+    return parts
+
+
+def gemm_wgrad_supported(x3, go3):
+    B, Cin, P = x3.shape
+    return (settings.USE_MFMA_GEMM_TRAIN and x3.is_cuda and x3.dtype == torch.float32 and P % 128 == 0 and Cin % 256 == 0
+            and go3.shape[1] >= 64 and 2.0 * B * P * Cin * go3.shape[1] >= 2e9)
+
+
+def gemm_wgrad(x3, go3):
+    """dW f32[Cout,Cin] = sum_b go3[b] . x3[b]^T (x3 f32[B,Cin,P], go3 f32[B,Cout,P]) on the split-bf16 MFMA GEMM with the pixels as the
+    contraction axis (include/gdm.h gdm_wgrad_pack_x1_hip): the weight gradient of a 1x1 convolution / of `wx`."""
+    x3 = _dev(x3, torch.float32, "x")
+    go3 = _dev(go3, torch.float32, "grad_out")
+    B, Cin, P = x3.shape
+    Cout = go3.shape[1]
+    L = _lib.lib()
+    nx, ng = L.gdm_wgrad_x1_bytes(B, Cin, P), L.gdm_wgrad_go_bytes(B, Cout, P // 32, 32)
+    if nx == 0 or ng == 0 or Cin % 256 != 0:
+        raise ValueError("gemm_wgrad: unsupported shape x %s grad_out %s" % (tuple(x3.shape), tuple(go3.shape)))
+    xpk = torch.empty(nx, dtype=torch.uint8, device=x3.device)
+    gpk = torch.empty(ng, dtype=torch.uint8, device=x3.device)
+    check(L.gdm_wgrad_pack_x1_hip(x3.data_ptr(), B, Cin, P, xpk.data_ptr(), _stream()), "gdm_wgrad_pack_x1_hip")
+    check(L.gdm_wgrad_pack_go_hip(go3.data_ptr(), B, Cout, P // 32, 32, gpk.data_ptr(), _stream()), "gdm_wgrad_pack_go_hip")
+    nchunk = B * P // 128
+    parts = _wgrad_parts(nchunk, (Cin // 256) * ((Cout + 127) // 128))
+    n = nchunk // parts
+    coutp = (Cout + 127) // 128 * 128
+    out = torch.empty((parts, Cout, Cin), dtype=torch.float32, device=x3.device)
+    check(L.gdm_conv1x1_packed_wb_hip(xpk.data_ptr(), gpk.data_ptr(), n * coutp * 512, parts, 128 * n, Cout, 1, Cin, out.data_ptr(), _stream()),
+          "gdm_conv1x1_packed_wb_hip")
+    return out[0] if parts == 1 else out.sum(0)
+
+
+def _gemm_fwd_mfma_ok(cin, cout, n, B):
+    return settings.USE_MFMA_GEMM_TRAIN and gemm_supported(cin, cout, n) and 2.0 * B * n * cin * cout >= 2e9
+
+
+class _WxTrain(torch.autograd.Function):
+    """y[b] = W . x[b] under autograd with the three products on the split-bf16 MFMA GEMM where they are large (>= 2 GFLOP: the tap
+    GEMMs of PSPUpsample, the PSP bottleneck, the 512 / 1024-channel fusion convolutions), on hipBLASLt fp32 batched GEMMs otherwise:
+    forward W . x, input gradient W^T . go, weight gradient sum_b go[b] . x[b]^T (pixels as the contraction axis)."""
+
+    @staticmethod
+    def forward(ctx, x3, w2):
+        ctx.save_for_backward(x3, w2)
+        B, Cin, n = x3.shape
+        Cout = w2.shape[0]
+        if x3.is_cuda and _gemm_fwd_mfma_ok(Cin, Cout, n, B):
+            return gemm_bf16x3(x3, gemm_pack_weight(w2), Cout)
+        return torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x3)
+
+    @staticmethod
+    def backward(ctx, go):
+        x3, w2 = ctx.saved_tensors
+        B, Cin, n = x3.shape
+        Cout = w2.shape[0]
+        go = go.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if x3.is_cuda and _gemm_fwd_mfma_ok(Cout, Cin, n, B):
+                gx = gemm_bf16x3(go, gemm_pack_weight(w2.t().contiguous()), Cin)
+            else:
+                gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go)
+        if ctx.needs_input_grad[1]:
+            if gemm_wgrad_supported(x3, go):
+                gw = gemm_wgrad(x3, go)
+            else:
+                gw = torch.bmm(go, x3.transpose(1, 2)).sum(0)
+        return gx, gw
 
 
 class _Conv1x1Train(torch.autograd.Function):
@@ -856,8 +937,17 @@ def conv1x1_train_supported(conv, x):
 
 
 def conv1x1_train(conv, x):
-    """Differentiable 1x1 convolution of an nn.Conv1d / nn.Conv2d module as batched GEMMs (see _Conv1x1Train)."""
+    """Differentiable 1x1 convolution of an nn.Conv1d / nn.Conv2d module as batched GEMMs (see _Conv1x1Train); large layers take the
+    split-bf16 MFMA GEMM for all three products (_WxTrain)."""
     w = conv.weight
+    B, Cin = x.shape[0], x.shape[1]
+    n = x.numel() // (B * Cin)
+    Cout = w.shape[0]
+    if x.is_cuda and (_gemm_fwd_mfma_ok(Cin, Cout, n, B) or _gemm_fwd_mfma_ok(Cout, Cin, n, B)):
+        y = _WxTrain.apply(x.reshape(B, Cin, n).contiguous(), w.reshape(Cout, Cin).contiguous())
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, -1, 1)
+        return y.view(B, Cout, *x.shape[2:])
     return _Conv1x1Train.apply(x.contiguous(), w.reshape(w.shape[0], w.shape[1]), conv.bias)
 
 

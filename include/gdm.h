@@ -505,6 +505,11 @@ size_t gdm_wgrad_x_bytes(int B, int Cin, int H, int W);
 size_t gdm_wgrad_go_bytes(int B, int Cout, int H, int W);
 int gdm_wgrad_pack_x_hip(const float* x, int B, int Cin, int H, int W, void* out, void* stream);
 int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, int W, void* out, void* stream);
+/* The 1x1 case, dW[co,ci] = sum_{b,p} go[b,co,p] * x[b,ci,p] (x f32[B,Cin,P], P % 128 == 0, Cin % 32 == 0): xpk = gdm_wgrad_pack_x1_hip
+ * (gdm_wgrad_x1_bytes bytes), gpk = gdm_wgrad_pack_go_hip(go, B, Cout, P/32, 32), then
+ * gdm_conv1x1_packed_wb_hip(xpk, gpk, n*CoutP*512, parts, 128*n, Cout, 1, Cin, out f32[parts, Cout, Cin], stream) (Cin % 256 == 0). */
+size_t gdm_wgrad_x1_bytes(int B, int Cin, int P);
+int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void* out, void* stream);
 /* gdm_conv1x1_packed_hip without epilogue, NCHW output, with the weights of image b at wpk + b*w_bstride (H*W % 256 == 0). */
 int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long w_bstride, int B, int Cin, int Cout, int H, int W, float* out,
                               void* stream);

@@ -454,3 +454,47 @@ def test_conv3x3_weight_gradient_on_the_mfma_gemm_equals_autograd(B, Cin, Cout, 
     assert got.shape == want.shape
     assert (got.double() - want).norm().item() < 3e-5 * want.norm().item()
     assert (got.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,P", [(2, 256, 256, 4096), (3, 1024, 2304, 256), (1, 512, 72, 16384), (24, 1024, 2304, 256)])
+def test_pixel_contraction_weight_gradient_of_a_1x1_product_equals_fp64(B, Cin, Cout, P):
+    """ops.gemm_wgrad (dW = sum_b go[b] . x[b]^T with the pixels as the contraction axis of the split-bf16 MFMA GEMM) == the fp64 product:
+    relative L2 3e-5, max 1e-4 of the gradient's scale."""
+    from geometric_aware_dense_matching_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + P)
+    x = torch.randn(B, Cin, P, generator=g).cuda()
+    go = torch.randn(B, Cout, P, generator=g).cuda()
+    got = ops.gemm_wgrad(x, go)
+    want = torch.bmm(go.double(), x.double().transpose(1, 2)).sum(0)
+    assert got.shape == want.shape
+    assert (got.double() - want).norm().item() < 3e-5 * want.norm().item()
+    assert (got.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,n,conv", [(4, 1024, 2304, 256, False), (2, 512, 256, 4096, False), (2, 256, 512, 4096, True), (2, 64, 32, 1000, False)])
+def test_wx_training_products_on_the_mfma_gemm_equal_fp64_autograd(B, Cin, Cout, n, conv):
+    """ops.wx / ops.conv1x1_train under autograd (forward, input gradient, weight gradient each on the split-bf16 MFMA GEMM where large,
+    on a batched fp32 GEMM otherwise) == fp64 autograd of the same product, followed by an in-place activation (a smooth one: at a kink a 1e-5
+    difference of the product picks the other slope for that element): 1e-4 of each scale."""
+    from geometric_aware_dense_matching_amd import ops
+    torch.manual_seed(Cin + n)
+    x = torch.randn(B, Cin, n, device="cuda", requires_grad=True)
+    wgt = torch.randn(B, Cout, n, device="cuda")
+    if conv:
+        m = torch.nn.Conv1d(Cin, Cout, 1, bias=True).cuda()
+        y = torch.tanh_(ops.conv1x1_train(m, x))
+        w = m.weight
+    else:
+        w = (torch.randn(Cout, Cin, device="cuda") / Cin ** 0.5).requires_grad_(True)
+        y = torch.tanh(ops.wx(w, x))
+    (y * wgt).sum().backward()
+    got = [y.detach().double(), x.grad.double(), w.grad.double().reshape(Cout, Cin)]
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = w.detach().double().reshape(Cout, Cin).requires_grad_(True)
+    y64 = torch.matmul(w64, x64)
+    if conv:
+        y64 = y64 + m.bias.detach().double().view(1, -1, 1)
+    y64 = torch.tanh(y64)
+    (y64 * wgt.double()).sum().backward()
+    for a, b in zip(got, [y64.detach(), x64.grad, w64.grad]):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
