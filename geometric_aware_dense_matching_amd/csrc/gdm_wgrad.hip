@@ -118,6 +118,144 @@ __global__ __launch_bounds__(256) void wgrad_pack_x1_kernel(const float* __restr
     }
 }
 
+// Small-channel products (Cout, Cin <= a few hundred, millions of pixels: the 1x1 layers of the 64 / 32-channel full-resolution stages and
+// of the point branch): HBM-bound, so no re-layout pass -- a wave reads its MFMA fragments straight from the fp32 rows (lane = row l & 15,
+// 8 consecutive pixels 8 (l >> 4) .. of a 32-pixel k-step = two 16-byte loads), splits them to bf16 hi / lo in registers and accumulates
+// TM x TN tiles of 16 x 16.  A workgroup = 4 waves = 4 interleaved pixel slices of one (K split, tile block); the waves' tiles are
+// added through LDS in a fixed order and written as one partial product [split][Cout][Cin] (the caller adds the splits).
+// bias (optional) = row sums of go, from the same loads: partial [split][Cout], written by the workgroups of tile column 0.
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restrict__ go, long go_bs, const float* __restrict__ x, long x_bs,
+                                                           int Cout, int Cin, int P, long nsteps, int nsplit, float* __restrict__ part,
+                                                           float* __restrict__ bias_part)
+{
+    __shared__ float red[3][TM * TN * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int split = blockIdx.x;
+    const int nbn = (Cin + 16 * TN - 1) / (16 * TN);
+    const int bm = blockIdx.y / nbn, bn = blockIdx.y - bm * nbn;
+    const int spp = P / 32;                                          // k-steps per image
+    // this wave's k-steps: split's range [s0, s1), wave w takes s0 + w, s0 + w + 4, ...
+    const long s0 = nsteps * split / nsplit, s1 = nsteps * (split + 1) / nsplit;
+    int rowa[TM], rowb[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) rowa[m] = min((bm * TM + m) * 16 + l16, Cout - 1);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) rowb[n] = min((bn * TN + n) * 16 + l16, Cin - 1);
+    wg_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.f;
+    float bsum[TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) bsum[m] = 0.f;
+
+    struct Frags { float4 a[TM][2], b[TN][2]; };
+    Frags f0, f1;                                                   // two named buffers (an index would send them to scratch)
+    auto load = [&](Frags& f, long ks) {
+        const long b = ks / spp;
+        const int p0 = (int)(ks - b * spp) * 32 + 8 * kg;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const float4* r = reinterpret_cast<const float4*>(go + b * go_bs + (long)rowa[m] * P + p0);
+            f.a[m][0] = r[0]; f.a[m][1] = r[1];
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const float4* r = reinterpret_cast<const float4*>(x + b * x_bs + (long)rowb[n] * P + p0);
+            f.b[n][0] = r[0]; f.b[n][1] = r[1];
+        }
+    };
+    auto split8 = [](const float4& a, const float4& b, wg_u32x4& hi, wg_u32x4& lo) {
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        gdm_split2(a.x, a.y, h0, l0); gdm_split2(a.z, a.w, h1, l1); gdm_split2(b.x, b.y, h2, l2); gdm_split2(b.z, b.w, h3, l3);
+        hi = wg_u32x4{h0, h1, h2, h3}; lo = wg_u32x4{l0, l1, l2, l3};
+    };
+    auto compute = [&](const Frags& f) {
+        wg_u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            split8(f.a[m][0], f.a[m][1], ah[m], al[m]);
+            const float4 u = f.a[m][0], v = f.a[m][1];
+            bsum[m] += ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) split8(f.b[n][0], f.b[n][1], bh[n], bl[n]);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                wg_f32x4 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, ah[m]), __builtin_bit_cast(wg_bf16x8, bl[n]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, al[m]), __builtin_bit_cast(wg_bf16x8, bh[n]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, ah[m]), __builtin_bit_cast(wg_bf16x8, bh[n]), c, 0, 0, 0);
+                acc[m][n] = c;
+            }
+    };
+    long ks = s0 + wave;
+    if (ks < s1) load(f0, ks);
+    for (; ks < s1; ks += 8) {
+        if (ks + 4 < s1) load(f1, ks + 4);
+        compute(f0);
+        if (ks + 4 < s1) {
+            if (ks + 8 < s1) load(f0, ks + 8);
+            compute(f1);
+        }
+    }
+    // waves 1..3 -> LDS, wave 0 adds them in order and stores; accumulator (m, n): lane -> column 16 n + l16 (ci), rows 16 m + 4 kg + r (co)
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][((m * TN + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+    }
+    // row sums: lanes l16 + 16 kg hold the four pixel groups of row l16 -> the kg == 0 lane
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        bsum[m] += __shfl_xor(bsum[m], 16);
+        bsum[m] += __shfl_xor(bsum[m], 32);
+    }
+    __shared__ float bred[3][TM * 16];
+    if (wave > 0 && kg == 0) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) bred[wave - 1][m * 16 + l16] = bsum[m];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float* o = part + (long)split * Cout * Cin;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int ci = (bn * TN + n) * 16 + l16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (bm * TM + m) * 16 + 4 * kg + r;
+                const int e = ((m * TN + n) * 4 + r) * 64 + lane;
+                const float v = ((acc[m][n][r] + red[0][e]) + red[1][e]) + red[2][e];
+                if (co < Cout && ci < Cin) o[(long)co * Cin + ci] = v;
+            }
+        }
+    if (bias_part && bn == 0 && kg == 0) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int co = (bm * TM + m) * 16 + l16;
+            const float v = ((bsum[m] + bred[0][m * 16 + l16]) + bred[1][m * 16 + l16]) + bred[2][m * 16 + l16];
+            if (co < Cout) bias_part[(long)split * Cout + co] = v;
+        }
+    }
+}
+
 bool shape_ok(int B, int C, int H, int W)
 {
     return B >= 1 && C >= 1 && H >= 1 && (W == 32 || W == 64) && (H * W) % 128 == 0;
@@ -175,4 +313,33 @@ extern "C" int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void
     dim3 grid(B * (P / 128), gdm_cdiv(Cin, 64));
     hipLaunchKernelGGL(wgrad_pack_x1_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, Cin, P, (unsigned char*)out);
     return gdm_launch_status("wgrad_pack_x1_kernel");
+}
+
+extern "C" int gdm_wgrad_direct_hip(const float* go, long go_bstride, const float* x, long x_bstride, int B, int Cout, int Cin, int P,
+                                    int nsplit, float* partial, float* bias_partial, void* stream)
+{
+    GDM_CHECK_ARG(go && x && partial, "gdm_wgrad_direct_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cout >= 1 && Cin >= 1 && P >= 32 && P % 32 == 0 && nsplit >= 1 && nsplit <= 65535,
+                  "gdm_wgrad_direct_hip: unsupported shape B=%d Cout=%d Cin=%d P=%d nsplit=%d (P %% 32 == 0)", B, Cout, Cin, P, nsplit);
+    GDM_CHECK_ARG(((uintptr_t)go & 15) == 0 && ((uintptr_t)x & 15) == 0 && go_bstride % 4 == 0 && x_bstride % 4 == 0,
+                  "gdm_wgrad_direct_hip: rows must be 16-byte aligned");
+    const long nsteps = (long)B * (P / 32);
+    GDM_CHECK_ARG(nsplit <= nsteps, "gdm_wgrad_direct_hip: more splits (%d) than 32-pixel steps (%ld)", nsplit, nsteps);
+    const int tm = Cout > 32 ? 4 : (Cout > 16 ? 2 : 1), tn = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
+    const int nbm = gdm_cdiv(Cout, 16 * tm), nbn = gdm_cdiv(Cin, 16 * tn);
+    GDM_CHECK_ARG((long)nbm * nbn <= 65535, "gdm_wgrad_direct_hip: too many tile blocks");
+    dim3 grid(nsplit, nbm * nbn);
+#define GDM_WD(TM, TN) hipLaunchKernelGGL((wgrad_direct_kernel<TM, TN>), grid, dim3(256), 0, (hipStream_t)stream, go, go_bstride, x, x_bstride, \
+                                          Cout, Cin, P, nsteps, nsplit, partial, bias_partial)
+    if (tm == 4 && tn == 4) GDM_WD(4, 4);
+    else if (tm == 4 && tn == 2) GDM_WD(4, 2);
+    else if (tm == 4 && tn == 1) GDM_WD(4, 1);
+    else if (tm == 2 && tn == 4) GDM_WD(2, 4);
+    else if (tm == 2 && tn == 2) GDM_WD(2, 2);
+    else if (tm == 2 && tn == 1) GDM_WD(2, 1);
+    else if (tm == 1 && tn == 4) GDM_WD(1, 4);
+    else if (tm == 1 && tn == 2) GDM_WD(1, 2);
+    else GDM_WD(1, 1);
+#undef GDM_WD
+    return gdm_launch_status("wgrad_direct_kernel");
 }

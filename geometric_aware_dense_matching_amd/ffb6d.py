@@ -264,6 +264,15 @@ class FFB6DEmb(nn.Module):
             # the last stage (up_3 + final) is a per-pixel function of a 3x3 neighbourhood and only the N `choose` pixels of its
             # full-resolution output are kept (reference ffb6d.py:266-285): evaluate it there, on the pixel-major fused map
             rgb_emb_c = self._final_at_choose(rgb_emb, (hr, wr), inputs["choose"])
+        elif self._gathered_final_ok():
+            # training (and unfused inference): up_3 needs the whole map (its BatchNorm statistics), but FinalStage -- 1x1 convolution +
+            # LogSoftmax over channels -- is a per-pixel function, so it commutes with the `choose` gather (reference ffb6d.py:266-285
+            # applies it to all H*W pixels and keeps N): gather first, and forward and backward of the stage touch N pixels, not H*W
+            last = self.cnn_up_stages[n_up - 1]
+            rgb_emb = last[0](rgb_emb)
+            bs, di, _, _ = rgb_emb.size()
+            rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+            rgb_emb_c = last[1](rgb_emb_c.unsqueeze(-1)).squeeze(-1)
         else:
             rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
             bs, di, _, _ = rgb_emb.size()
@@ -271,6 +280,11 @@ class FFB6DEmb(nn.Module):
         if parts:
             return rgb_emb_c, p_emb
         return torch.cat([rgb_emb_c, p_emb], dim=1)
+
+    def _gathered_final_ok(self):
+        from .cnn import FinalStage
+        last = self.cnn_up_stages[len(self.rndla_up_stages) - 1]
+        return settings.USE_GATHERED_FINAL and len(last) == 2 and isinstance(last[1], FinalStage)
 
     def _sparse_final_ok(self, rgb):
         """Inference with folded BatchNorm, the last stage = PSPUpsample(64 -> 64) + FinalStage(64 -> 64) and the last fusion on the

@@ -858,6 +858,36 @@ def gemm_wgrad(x3, go3):
     return out[0] if parts == 1 else out.sum(0)
 
 
+def wgrad_direct_supported(x3, go3):
+    """Small-channel, many-pixel products: the HBM-bound form that reads the fp32 rows once (include/gdm.h gdm_wgrad_direct_hip)."""
+    B, Cin, P = x3.shape
+    Cout = go3.shape[1]
+    return (settings.USE_DIRECT_WGRAD and x3.is_cuda and x3.dtype == torch.float32 and go3.dtype == torch.float32 and P % 32 == 0
+            and Cin <= 128 and Cout <= 128 and B * P >= 16384 and _rows_ok(x3) and _rows_ok(go3))
+
+
+def _rows_ok(t):
+    """[B,C,P] with contiguous rows of P floats, channel stride P, any batch stride (a channel slice of a concatenation qualifies)."""
+    return t.stride(2) == 1 and t.stride(1) == t.shape[2] and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def wgrad_direct(x3, go3, bias=False):
+    """(dW f32[Cout,Cin], db f32[Cout] or None) = (sum_{b,p} go3[b,:,p] x3[b,:,p]^T, sum_{b,p} go3[b,:,p]) in one pass over the fp32
+    rows (split-bf16 MFMA, K split over workgroups, partials added in fixed order)."""
+    B, Cin, P = x3.shape
+    Cout = go3.shape[1]
+    nsteps = B * (P // 32)
+    tm = 4 if Cout > 32 else (2 if Cout > 16 else 1)
+    tn = 4 if Cin > 32 else (2 if Cin > 16 else 1)
+    blocks = -(-Cout // (16 * tm)) * -(-Cin // (16 * tn))
+    nsplit = max(1, min(nsteps // 8, 1024 // blocks))
+    part = torch.empty((nsplit, Cout, Cin), dtype=torch.float32, device=x3.device)
+    bpart = torch.empty((nsplit, Cout), dtype=torch.float32, device=x3.device) if bias else None
+    check(_lib.lib().gdm_wgrad_direct_hip(go3.data_ptr(), go3.stride(0), x3.data_ptr(), x3.stride(0), B, Cout, Cin, P, nsplit,
+                                          part.data_ptr(), bpart.data_ptr() if bias else None, _stream()), "gdm_wgrad_direct_hip")
+    return part.sum(0), (bpart.sum(0) if bias else None)
+
+
 def _gemm_fwd_mfma_ok(cin, cout, n, B):
     return settings.USE_MFMA_GEMM_TRAIN and gemm_supported(cin, cout, n) and 2.0 * B * n * cin * cout >= 2e9
 
@@ -891,6 +921,8 @@ class _WxTrain(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if gemm_wgrad_supported(x3, go):
                 gw = gemm_wgrad(x3, go)
+            elif wgrad_direct_supported(x3, go):
+                gw = wgrad_direct(x3, go)[0]
             else:
                 gw = torch.bmm(go, x3.transpose(1, 2)).sum(0)
         return gx, gw
@@ -924,9 +956,13 @@ class _Conv1x1Train(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go3).view(ctx.xshape)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and wgrad_direct_supported(x3, go3):
+            gw, gb = wgrad_direct(x3, go3, bias=want_gb)             # weight and bias gradient from one read of go
+            return gx, gw, gb
         if ctx.needs_input_grad[1]:
             gw = torch.bmm(go3, x3.transpose(1, 2)).sum(0)            # [B, Cout, Cin] partials: <= 25 MB for every layer but one
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_gb:
             gb = go3.sum((0, 2))
         return gx, gw, gb
 

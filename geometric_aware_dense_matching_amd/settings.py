@@ -24,6 +24,8 @@ the initial values.
                                                           (default: evaluated at the chosen pixels only -- inference, 1/32 of the pixels)
     USE_FUSED_HEADS            GDM_FUSED_HEADS            the nine per-point 1x1 convolutions after the embedding as library GEMMs + BN kernels
     USE_MFMA_WGRAD             GDM_MFMA_WGRAD             weight gradient of the trunk's 3x3 convolutions at Cin = 256 / 512 on MIOpen (fp32 implicit GEMM)
+    USE_GATHERED_FINAL         GDM_GATHERED_FINAL         training: FinalStage (1x1 conv + LogSoftmax) on the N chosen pixels    FinalStage on all H*W pixels, then the gather
+    USE_DIRECT_WGRAD           GDM_DIRECT_WGRAD           training: weight (+ bias) gradient of the small-channel 1x1 layers in one pass over fp32 rows        batched fp32 GEMM + sums
     USE_MFMA_GEMM_TRAIN        GDM_MFMA_GEMM_TRAIN        training: the large 1x1 products (PSPUpsample tap GEMMs, PSP bottleneck, 512 / 1024-channel fusion layers)
                                                           forward / input gradient / weight gradient on hipBLASLt fp32 batched GEMMs
     USE_GEMM_CONV1X1_TRAIN     GDM_GEMM_CONV1X1_TRAIN     training 1x1 convolutions through torch's convolution (MIOpen wgrad / bwd-data + NHWC transposes)
@@ -60,13 +62,15 @@ USE_OWN_STEM = _flag("GDM_OWN_STEM")
 USE_GEMM_CONV1X1_TRAIN = _flag("GDM_GEMM_CONV1X1_TRAIN")
 USE_MFMA_WGRAD = _flag("GDM_MFMA_WGRAD")
 USE_MFMA_GEMM_TRAIN = _flag("GDM_MFMA_GEMM_TRAIN")
+USE_GATHERED_FINAL = _flag("GDM_GATHERED_FINAL")
+USE_DIRECT_WGRAD = _flag("GDM_DIRECT_WGRAD")
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
-                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN", "USE_MFMA_WGRAD", "USE_MFMA_GEMM_TRAIN")
+                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN", "USE_MFMA_WGRAD", "USE_MFMA_GEMM_TRAIN", "USE_GATHERED_FINAL", "USE_DIRECT_WGRAD")
 # the switches behind which split-bf16 (x3, fp32 accumulate) products run in the eval forward: all off = fp32 products everywhere
 # (hipBLASLt / MIOpen / fp32 FMA kernels); the matching kernel's precision is its own argument (matching.match_frames(precision=))
 SPLIT_BF16_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED",

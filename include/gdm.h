@@ -510,6 +510,12 @@ int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, int W, void* 
  * gdm_conv1x1_packed_wb_hip(xpk, gpk, n*CoutP*512, parts, 128*n, Cout, 1, Cin, out f32[parts, Cout, Cin], stream) (Cin % 256 == 0). */
 size_t gdm_wgrad_x1_bytes(int B, int Cin, int P);
 int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void* out, void* stream);
+/* Small-channel form with no re-layout pass (HBM-bound; the 1x1 layers of the 32 / 64-channel full-resolution stages and of the point
+ * branch under training): partial[s][co][ci] = sum over the s-th of nsplit slices of the B*P/32 pixel steps of go[b,co,p] * x[b,ci,p]
+ * (rows of P floats, batch strides in elements, P % 32 == 0, split-bf16 MFMA); bias_partial[s][co] (optional) = the row sums of go.
+ * The caller adds the nsplit partials. */
+int gdm_wgrad_direct_hip(const float* go, long go_bstride, const float* x, long x_bstride, int B, int Cout, int Cin, int P,
+                         int nsplit, float* partial, float* bias_partial, void* stream);
 /* gdm_conv1x1_packed_hip without epilogue, NCHW output, with the weights of image b at wpk + b*w_bstride (H*W % 256 == 0). */
 int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long w_bstride, int B, int Cin, int Cout, int H, int W, float* out,
                               void* stream);

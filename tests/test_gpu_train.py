@@ -498,3 +498,24 @@ def test_wx_training_products_on_the_mfma_gemm_equal_fp64_autograd(B, Cin, Cout,
     (y64 * wgt.double()).sum().backward()
     for a, b in zip(got, [y64.detach(), x64.grad, w64.grad]):
         assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,P,sliced", [(3, 32, 32, 65536, False), (2, 64, 128, 16384, True), (24, 128, 128, 4096, False), (2, 40, 24, 8192, False),
+                                                 (1, 8, 3, 16384, True), (5, 64, 64, 4128, False)])
+def test_direct_weight_and_bias_gradient_of_small_channel_layers_equals_fp64(B, Cin, Cout, P, sliced):
+    """ops.wgrad_direct (one pass over the fp32 rows, fragments split to bf16 hi / lo in registers, K split over workgroups) ==
+    the fp64 products; `sliced`: the operands are channel slices of wider tensors (batch stride != C * P), as the gradient of a
+    concatenation hands them over.  Relative L2 3e-5, max 1e-4 of the scale."""
+    from geometric_aware_dense_matching_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + P)
+    xw = torch.randn(B, Cin + (16 if sliced else 0), P, generator=g).cuda()
+    gw_ = torch.randn(B, Cout + (8 if sliced else 0), P, generator=g).cuda()
+    x, go = xw[:, 4:4 + Cin] if sliced else xw, gw_[:, 8:8 + Cout] if sliced else gw_
+    assert ops.wgrad_direct_supported(x, go)
+    got_w, got_b = ops.wgrad_direct(x, go, bias=True)
+    want_w = torch.bmm(go.double(), x.double().transpose(1, 2)).sum(0)
+    want_b = go.double().sum((0, 2))
+    assert got_w.shape == want_w.shape and got_b.shape == want_b.shape
+    assert (got_w.double() - want_w).norm().item() < 3e-5 * want_w.norm().item()
+    assert (got_w.double() - want_w).abs().max().item() < 1e-4 * want_w.abs().max().item()
+    assert (got_b.double() - want_b).abs().max().item() < 1e-4 * max(1.0, want_b.abs().max().item())
