@@ -188,6 +188,7 @@ __global__ __launch_bounds__(GB) void gather_max_bwd_kernel(const float* __restr
 // points).  A block owns (batch item, LCH channels, one segment of the entries): LDS atomics while scanning, then one global
 // atomic per touched (source, channel).  10.6 ms -> see DESIGN.md of a 111 ms training step with the global-atomic form.
 constexpr int LCH = 4;
+template <bool VEC>
 __global__ __launch_bounds__(GB) void group_gather_bwd_lds_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
                                                                   int C, int n, long mk, long seg_len, float* __restrict__ gfeat)
 {
@@ -198,12 +199,42 @@ __global__ __launch_bounds__(GB) void group_gather_bwd_lds_kernel(const float* _
     for (int i = threadIdx.x; i < LCH * n; i += GB) accs[i] = 0.f;
     __syncthreads();
     const long e0 = (long)blockIdx.x * seg_len, e1 = min(mk, e0 + seg_len);
-    for (long e = e0 + threadIdx.x; e < e1; e += GB) {
-        int src = idx[(long)b * mk + e];
-        src = min(max(src, 0), n - 1);
-        for (int c = 0; c < nc; ++c) atomicAdd(&accs[c * n + src], go[((long)b * C + c0 + c) * mk + e]);
+    if (VEC) {
+        // four consecutive entries per thread and step (host: mk % 4 == 0, seg_len % 4 == 0, 16-byte aligned rows): the loads of a
+        // step -- one int4 of indices, one float4 per channel -- are issued together, the scan is a quarter as many dependent steps
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 4L * GB) {
+            const int4 s4 = *reinterpret_cast<const int4*>(idx + (long)b * mk + e);
+            float4 g[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c)
+                g[c] = c < nc ? *reinterpret_cast<const float4*>(go + ((long)b * C + c0 + c) * mk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int s0 = min(max(s4.x, 0), n - 1), s1 = min(max(s4.y, 0), n - 1), s2 = min(max(s4.z, 0), n - 1), s3 = min(max(s4.w, 0), n - 1);
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                if (c < nc) {
+                    atomicAdd(&accs[c * n + s0], g[c].x);
+                    atomicAdd(&accs[c * n + s1], g[c].y);
+                    atomicAdd(&accs[c * n + s2], g[c].z);
+                    atomicAdd(&accs[c * n + s3], g[c].w);
+                }
+            }
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += GB) {
+            int src = idx[(long)b * mk + e];
+            src = min(max(src, 0), n - 1);
+            for (int c = 0; c < nc; ++c) atomicAdd(&accs[c * n + src], go[((long)b * C + c0 + c) * mk + e]);
+        }
     }
     __syncthreads();
+    if (gridDim.x == 1) {
+        // one segment: this block is the only writer of its (batch item, channels) rows -- plain stores, zeros included
+        for (int i = threadIdx.x; i < nc * n; i += GB) {
+            const int c = i / n, j = i - c * n;
+            gfeat[((long)b * C + c0 + c) * n + j] = accs[i];
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < nc * n; i += GB) {
         const float v = accs[i];
         if (v != 0.f) {
@@ -407,8 +438,13 @@ extern "C" int gdm_group_gather_bwd_hip(const float* go, const int32_t* idx, int
         long nseg = gdm_cdiv(mk, seg_len);
         if (nseg > 65535) { nseg = 65535; seg_len = gdm_cdiv(mk, nseg); }
         dim3 grid((unsigned)nseg, gdm_cdiv(C, LCH), B);
-        hipLaunchKernelGGL(group_gather_bwd_lds_kernel, grid, dim3(GB), (size_t)n * LCH * sizeof(float), STREAM(stream), go, idx, C, n, mk,
-                           seg_len, gfeat);
+        const bool vec = mk % 4 == 0 && seg_len % 4 == 0 && (((uintptr_t)go | (uintptr_t)idx) & 15) == 0;
+        if (vec)
+            hipLaunchKernelGGL(group_gather_bwd_lds_kernel<true>, grid, dim3(GB), (size_t)n * LCH * sizeof(float), STREAM(stream), go, idx, C, n,
+                               mk, seg_len, gfeat);
+        else
+            hipLaunchKernelGGL(group_gather_bwd_lds_kernel<false>, grid, dim3(GB), (size_t)n * LCH * sizeof(float), STREAM(stream), go, idx, C, n,
+                               mk, seg_len, gfeat);
         return gdm_launch_status("group_gather_bwd_lds_kernel");
     }
     dim3 grid(gdm_cdiv(mk, GB), gdm_cdiv(C, CCHUNK), B);

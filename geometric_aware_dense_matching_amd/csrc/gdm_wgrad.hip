@@ -128,25 +128,32 @@ typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
 
-template <int TM, int TN>
+// TM x TN = 16 x 16 tiles per wave (<= 2 x 2: 110 registers, four waves per SIMD -- the kernel lives on bytes in flight), WM x WN = waves
+// side by side on the workgroup's (16 TM WM) x (16 TN WN) block of dW, the remaining 4 / (WM WN) waves = interleaved pixel slices.
+template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restrict__ go, long go_bs, const float* __restrict__ x, long x_bs,
                                                            int Cout, int Cin, int P, long nsteps, int nsplit, float* __restrict__ part,
                                                            float* __restrict__ bias_part)
 {
-    __shared__ float red[3][TM * TN * 256];
+    constexpr int KW = 4 / (WM * WN);                               // pixel slices inside the workgroup
+    __shared__ float red[KW > 1 ? (KW - 1) * WM * WN : 1][TM * TN * 256];
+    __shared__ float bred[KW > 1 ? (KW - 1) * WM * WN : 1][TM * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
+    const int wpos = wave % (WM * WN), kw = wave / (WM * WN);       // position in the block, pixel slice
+    const int wm = wpos / WN, wn = wpos - wm * WN;
     const int split = blockIdx.x;
-    const int nbn = (Cin + 16 * TN - 1) / (16 * TN);
+    const int nbn = (Cin + 16 * TN * WN - 1) / (16 * TN * WN);
     const int bm = blockIdx.y / nbn, bn = blockIdx.y - bm * nbn;
+    const int tm0 = (bm * WM + wm) * TM, tn0 = (bn * WN + wn) * TN;  // first tile row / column of this wave
     const int spp = P / 32;                                          // k-steps per image
-    // this wave's k-steps: split's range [s0, s1), wave w takes s0 + w, s0 + w + 4, ...
+    // this wave's k-steps: the split's range [s0, s1), slice kw takes s0 + kw, s0 + kw + KW, ...
     const long s0 = nsteps * split / nsplit, s1 = nsteps * (split + 1) / nsplit;
     int rowa[TM], rowb[TN];
 #pragma unroll
-    for (int m = 0; m < TM; ++m) rowa[m] = min((bm * TM + m) * 16 + l16, Cout - 1);
+    for (int m = 0; m < TM; ++m) rowa[m] = min((tm0 + m) * 16 + l16, Cout - 1);
 #pragma unroll
-    for (int n = 0; n < TN; ++n) rowb[n] = min((bn * TN + n) * 16 + l16, Cin - 1);
+    for (int n = 0; n < TN; ++n) rowb[n] = min((tn0 + n) * 16 + l16, Cin - 1);
     wg_f32x4 acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
     for (int m = 0; m < TM; ++m) bsum[m] = 0.f;
 
     struct Frags { float4 a[TM][2], b[TN][2]; };
-    Frags f0, f1;                                                   // two named buffers (an index would send them to scratch)
+    Frags f0, f1, f2;                                               // named buffers (an index would send them to scratch): two steps in flight
     auto load = [&](Frags& f, long ks) {
         const long b = ks / spp;
         const int p0 = (int)(ks - b * spp) * 32 + 8 * kg;
@@ -200,57 +207,69 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
                 acc[m][n] = c;
             }
     };
-    long ks = s0 + wave;
+    long ks = s0 + kw;
     if (ks < s1) load(f0, ks);
-    for (; ks < s1; ks += 8) {
-        if (ks + 4 < s1) load(f1, ks + 4);
+    if (ks + KW < s1) load(f1, ks + KW);
+    for (; ks < s1; ks += 3 * KW) {
+        if (ks + 2 * KW < s1) load(f2, ks + 2 * KW);
         compute(f0);
-        if (ks + 4 < s1) {
-            if (ks + 8 < s1) load(f0, ks + 8);
-            compute(f1);
-        }
+        if (ks + KW >= s1) break;
+        if (ks + 3 * KW < s1) load(f0, ks + 3 * KW);
+        compute(f1);
+        if (ks + 2 * KW >= s1) break;
+        if (ks + 4 * KW < s1) load(f1, ks + 4 * KW);
+        compute(f2);
     }
-    // waves 1..3 -> LDS, wave 0 adds them in order and stores; accumulator (m, n): lane -> column 16 n + l16 (ci), rows 16 m + 4 kg + r (co)
-    if (wave > 0) {
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave - 1][((m * TN + n) * 4 + r) * 64 + lane] = acc[m][n][r];
-    }
-    // row sums: lanes l16 + 16 kg hold the four pixel groups of row l16 -> the kg == 0 lane
+    // row sums: lanes l16 + 16 kg hold the four pixel groups of row l16 -> every lane
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         bsum[m] += __shfl_xor(bsum[m], 16);
         bsum[m] += __shfl_xor(bsum[m], 32);
     }
-    __shared__ float bred[3][TM * 16];
-    if (wave > 0 && kg == 0) {
+    // slices 1.. -> LDS, slice 0 adds them in order and stores; accumulator (m, n): lane -> column 16 n + l16 (ci), rows 16 m + 4 kg + r (co)
+    if (KW > 1) {
+        if (kw > 0) {
+            const int slot = (kw - 1) * WM * WN + wpos;
 #pragma unroll
-        for (int m = 0; m < TM; ++m) bred[wave - 1][m * 16 + l16] = bsum[m];
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[slot][((m * TN + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+            if (kg == 0) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m) bred[slot][m * 16 + l16] = bsum[m];
+            }
+        }
+        __syncthreads();
+        if (kw != 0) return;
     }
-    __syncthreads();
-    if (wave != 0) return;
     float* o = part + (long)split * Cout * Cin;
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
-            const int ci = (bn * TN + n) * 16 + l16;
+            const int ci = (tn0 + n) * 16 + l16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = (bm * TM + m) * 16 + 4 * kg + r;
-                const int e = ((m * TN + n) * 4 + r) * 64 + lane;
-                const float v = ((acc[m][n][r] + red[0][e]) + red[1][e]) + red[2][e];
+                const int co = (tm0 + m) * 16 + 4 * kg + r;
+                float v = acc[m][n][r];
+                if (KW > 1) {
+#pragma unroll
+                    for (int k = 1; k < KW; ++k) v += red[(k - 1) * WM * WN + wpos][((m * TN + n) * 4 + r) * 64 + lane];
+                }
                 if (co < Cout && ci < Cin) o[(long)co * Cin + ci] = v;
             }
         }
-    if (bias_part && bn == 0 && kg == 0) {
+    if (bias_part && bn == 0 && wn == 0 && kg == 0) {
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
-            const int co = (bm * TM + m) * 16 + l16;
-            const float v = ((bsum[m] + bred[0][m * 16 + l16]) + bred[1][m * 16 + l16]) + bred[2][m * 16 + l16];
+            const int co = (tm0 + m) * 16 + l16;
+            float v = bsum[m];
+            if (KW > 1) {
+#pragma unroll
+                for (int k = 1; k < KW; ++k) v += bred[(k - 1) * WM * WN + wpos][m * 16 + l16];
+            }
             if (co < Cout) bias_part[(long)split * Cout + co] = v;
         }
     }
@@ -325,21 +344,23 @@ extern "C" int gdm_wgrad_direct_hip(const float* go, long go_bstride, const floa
                   "gdm_wgrad_direct_hip: rows must be 16-byte aligned");
     const long nsteps = (long)B * (P / 32);
     GDM_CHECK_ARG(nsplit <= nsteps, "gdm_wgrad_direct_hip: more splits (%d) than 32-pixel steps (%ld)", nsplit, nsteps);
-    const int tm = Cout > 32 ? 4 : (Cout > 16 ? 2 : 1), tn = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
-    const int nbm = gdm_cdiv(Cout, 16 * tm), nbn = gdm_cdiv(Cin, 16 * tn);
+    // tiles per wave (<= 2 x 2), waves side by side (<= 2 x 2); see gdm_wgrad_direct_block()
+    const int tm = Cout > 16 ? 2 : 1, tn = Cin > 16 ? 2 : 1;
+    const int wm = Cout > 32 ? 2 : 1, wn = Cin > 32 ? 2 : 1;
+    const int nbm = gdm_cdiv(Cout, 16 * tm * wm), nbn = gdm_cdiv(Cin, 16 * tn * wn);
     GDM_CHECK_ARG((long)nbm * nbn <= 65535, "gdm_wgrad_direct_hip: too many tile blocks");
     dim3 grid(nsplit, nbm * nbn);
-#define GDM_WD(TM, TN) hipLaunchKernelGGL((wgrad_direct_kernel<TM, TN>), grid, dim3(256), 0, (hipStream_t)stream, go, go_bstride, x, x_bstride, \
-                                          Cout, Cin, P, nsteps, nsplit, partial, bias_partial)
-    if (tm == 4 && tn == 4) GDM_WD(4, 4);
-    else if (tm == 4 && tn == 2) GDM_WD(4, 2);
-    else if (tm == 4 && tn == 1) GDM_WD(4, 1);
-    else if (tm == 2 && tn == 4) GDM_WD(2, 4);
-    else if (tm == 2 && tn == 2) GDM_WD(2, 2);
-    else if (tm == 2 && tn == 1) GDM_WD(2, 1);
-    else if (tm == 1 && tn == 4) GDM_WD(1, 4);
-    else if (tm == 1 && tn == 2) GDM_WD(1, 2);
-    else GDM_WD(1, 1);
+#define GDM_WD(TM, TN, WM, WN) hipLaunchKernelGGL((wgrad_direct_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, (hipStream_t)stream, go, go_bstride, x, \
+                                                  x_bstride, Cout, Cin, P, nsteps, nsplit, partial, bias_partial)
+    if (wm == 2 && wn == 2) GDM_WD(2, 2, 2, 2);
+    else if (wm == 2 && tn == 2) GDM_WD(2, 2, 2, 1);
+    else if (wm == 2) GDM_WD(2, 1, 2, 1);
+    else if (wn == 2 && tm == 2) GDM_WD(2, 2, 1, 2);
+    else if (wn == 2) GDM_WD(1, 2, 1, 2);
+    else if (tm == 2 && tn == 2) GDM_WD(2, 2, 1, 1);
+    else if (tm == 2) GDM_WD(2, 1, 1, 1);
+    else if (tn == 2) GDM_WD(1, 2, 1, 1);
+    else GDM_WD(1, 1, 1, 1);
 #undef GDM_WD
     return gdm_launch_status("wgrad_direct_kernel");
 }

@@ -858,12 +858,17 @@ def gemm_wgrad(x3, go3):
     return out[0] if parts == 1 else out.sum(0)
 
 
-def wgrad_direct_supported(x3, go3):
-    """Small-channel, many-pixel products: the HBM-bound form that reads the fp32 rows once (include/gdm.h gdm_wgrad_direct_hip)."""
+def wgrad_direct_supported(x3, go3, bias=False):
+    """Small-channel, many-pixel products: the HBM-bound form that reads the fp32 rows once (include/gdm.h gdm_wgrad_direct_hip).
+    Kernel times at batch 24 (tools/bench_wgrad_direct.py under rocprofv3, own vs the fp32 batched GEMM; + 6-12 us for the sum of the
+    partials on both sides): 32x32 @ 65536 px 90 vs 320 us, 16x32 48 vs 166, 64x32 135 vs 167, 64x64 @ 16384 px 52 vs 57,
+    32x64 @ 4096 12 vs 23, 128x64 @ 16384 112 vs 103, 128x128 @ 4096 48 vs 41 -- so up to 64 x 64 channels, and up to 128 x 128 when the
+    bias gradient rides along (its separate reduction costs 34-490 us)."""
     B, Cin, P = x3.shape
     Cout = go3.shape[1]
+    lim = 128 if bias else 64
     return (settings.USE_DIRECT_WGRAD and x3.is_cuda and x3.dtype == torch.float32 and go3.dtype == torch.float32 and P % 32 == 0
-            and Cin <= 128 and Cout <= 128 and B * P >= 16384 and _rows_ok(x3) and _rows_ok(go3))
+            and Cin <= lim and Cout <= lim and B * P >= 16384 and _rows_ok(x3) and _rows_ok(go3))
 
 
 def _rows_ok(t):
@@ -877,10 +882,10 @@ def wgrad_direct(x3, go3, bias=False):
     B, Cin, P = x3.shape
     Cout = go3.shape[1]
     nsteps = B * (P // 32)
-    tm = 4 if Cout > 32 else (2 if Cout > 16 else 1)
-    tn = 4 if Cin > 32 else (2 if Cin > 16 else 1)
-    blocks = -(-Cout // (16 * tm)) * -(-Cin // (16 * tn))
-    nsplit = max(1, min(nsteps // 8, 1024 // blocks))
+    bm, bn = (64 if Cout > 32 else 32), (64 if Cin > 32 else 32)        # the workgroup's block of dW (csrc/gdm_wgrad.hip)
+    blocks = -(-Cout // bm) * -(-Cin // bn)
+    slices = 4 // ((2 if Cout > 32 else 1) * (2 if Cin > 32 else 1))    # pixel slices inside a workgroup
+    nsplit = max(1, min(nsteps // (8 * slices), 512 // blocks))           # >= 8 steps per wave, two workgroups per CU = one resident round
     part = torch.empty((nsplit, Cout, Cin), dtype=torch.float32, device=x3.device)
     bpart = torch.empty((nsplit, Cout), dtype=torch.float32, device=x3.device) if bias else None
     check(_lib.lib().gdm_wgrad_direct_hip(go3.data_ptr(), go3.stride(0), x3.data_ptr(), x3.stride(0), B, Cout, Cin, P, nsplit,
@@ -957,7 +962,7 @@ class _Conv1x1Train(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go3).view(ctx.xshape)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and wgrad_direct_supported(x3, go3):
+        if ctx.needs_input_grad[1] and wgrad_direct_supported(x3, go3, bias=want_gb):
             gw, gb = wgrad_direct(x3, go3, bias=want_gb)             # weight and bias gradient from one read of go
             return gx, gw, gb
         if ctx.needs_input_grad[1]:

@@ -26,6 +26,7 @@ the initial values.
     USE_MFMA_WGRAD             GDM_MFMA_WGRAD             weight gradient of the trunk's 3x3 convolutions at Cin = 256 / 512 on MIOpen (fp32 implicit GEMM)
     USE_GATHERED_FINAL         GDM_GATHERED_FINAL         training: FinalStage (1x1 conv + LogSoftmax) on the N chosen pixels    FinalStage on all H*W pixels, then the gather
     USE_DIRECT_WGRAD           GDM_DIRECT_WGRAD           training: weight (+ bias) gradient of the small-channel 1x1 layers in one pass over fp32 rows        batched fp32 GEMM + sums
+    USE_FUSED_ADAM             GDM_FUSED_ADAM             training: torch.optim.Adam(fused=True), one multi-tensor kernel                                        foreach Adam (~25 launches)
     USE_MFMA_GEMM_TRAIN        GDM_MFMA_GEMM_TRAIN        training: the large 1x1 products (PSPUpsample tap GEMMs, PSP bottleneck, 512 / 1024-channel fusion layers)
                                                           forward / input gradient / weight gradient on hipBLASLt fp32 batched GEMMs
     USE_GEMM_CONV1X1_TRAIN     GDM_GEMM_CONV1X1_TRAIN     training 1x1 convolutions through torch's convolution (MIOpen wgrad / bwd-data + NHWC transposes)
@@ -64,6 +65,7 @@ USE_MFMA_WGRAD = _flag("GDM_MFMA_WGRAD")
 USE_MFMA_GEMM_TRAIN = _flag("GDM_MFMA_GEMM_TRAIN")
 USE_GATHERED_FINAL = _flag("GDM_GATHERED_FINAL")
 USE_DIRECT_WGRAD = _flag("GDM_DIRECT_WGRAD")
+USE_FUSED_ADAM = _flag("GDM_FUSED_ADAM")
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))

@@ -511,7 +511,7 @@ def test_direct_weight_and_bias_gradient_of_small_channel_layers_equals_fp64(B, 
     xw = torch.randn(B, Cin + (16 if sliced else 0), P, generator=g).cuda()
     gw_ = torch.randn(B, Cout + (8 if sliced else 0), P, generator=g).cuda()
     x, go = xw[:, 4:4 + Cin] if sliced else xw, gw_[:, 8:8 + Cout] if sliced else gw_
-    assert ops.wgrad_direct_supported(x, go)
+    assert ops.wgrad_direct_supported(x, go, bias=True)
     got_w, got_b = ops.wgrad_direct(x, go, bias=True)
     want_w = torch.bmm(go.double(), x.double().transpose(1, 2)).sum(0)
     want_b = go.double().sum((0, 2))

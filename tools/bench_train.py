@@ -11,7 +11,7 @@ B = int(os.environ.get("B", 24)); N = int(os.environ.get("N", 4096)); M = int(os
 torch.backends.cudnn.benchmark = os.environ.get("FIND", "0") == "1"
 dev = torch.device("cuda", 0)
 model = GeoMatch(make_model_cfg(n_mesh_node=M, num_points=N), 1, model_points=synthetic.make_model_points(1, M)).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=os.environ.get("FUSED_ADAM", "1") == "1")
 ds = train_lm.SyntheticCrops(B, N, M, seed=0)
 batch = torch.utils.data.default_collate([ds[i] for i in range(B)])
 cu = train_lm.to_device(batch, dev)
