@@ -206,6 +206,236 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same stage with its two large products -- mlp2 (d/2 x d/2 per neighbour) and the attention logits (d x d per neighbour) -- on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products).  In the FMA form above every thread reads the whole d x 16 block of its point from
+// LDS (four 16-byte broadcast reads per 16 FMAs): the stage is bound by LDS issue, 35-63 us per launch for ~1 GFLOP.  Here a tile is
+// 16 channels x the 16 neighbours of one point:
+//   A fragment (W^T [in][out]):  lane l = output channel c0 + 4 (l & 3) + ((l & 15) >> 2), input row j + (l >> 4)     (global, 64-byte runs)
+//   B fragment (block in LDS):   lane l = neighbour l & 15, input row j + (l >> 4)                                     (256 contiguous bytes)
+//   accumulator:                 lane l = neighbour l & 15, register r = output channel c0 + 4 r + (l >> 4)
+// so the softmax over the neighbours and the weighted sum are reductions over the 16 lanes of a DPP row, and the feature the weighted
+// sum needs -- fcat[c0 + 4 r + (l >> 4)][l & 15] -- is one conflict-free LDS read (the rows of W are permuted for exactly that).
+// A workgroup owns P = 512 / D points (phases 1, 2 and 5 as above with two points per thread group); its 4 waves tile (channel tiles) x
+// (points).  One LDS dword read + one global dword load per 1024 products instead of 64 bytes of LDS per 16.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float lfa_f32x4;
+
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));   // row_mirror
+    return v;
+}
+// sum over the 16 lanes of a row in ONE fixed order for every lane: ((quad pairs) + other half of the 8) + other 8; the operand order of
+// each add is made lane-independent (lower lanes' partial first), so all 16 lanes hold bit-identical sums
+__device__ __forceinline__ float row16_sum(float v, int l16)
+{
+    float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v = (l16 & 1) ? o + v : v + o;
+    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v = (l16 & 2) ? o + v : v + o;
+    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    v = (l16 & 4) ? o + v : v + o;
+    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    v = (l16 & 8) ? o + v : v + o;
+    return v;
+}
+
+// acc[i][j] += W^T[:, row tile rt0 + WR i]^T . block of point pt0 + WP j, over KD input rows; src = LDS blocks [P][KD rows][16], wt = [KD][ROWS]
+template <int ROWS, int KD, int NRT, int NPT, int WR, int WP>
+__device__ __forceinline__ void lfa_tiles(const float* __restrict__ wt, const float* src, int src_pstride, int rt0, int pt0, int l16, int kq,
+                                          lfa_f32x4 (&acc)[NRT][NPT])
+{
+    const int perm = 4 * (l16 & 3) + (l16 >> 2);
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const float* wl = wt + (long)kq * ROWS + rt0 * 16 + perm;
+    const float* sl = src + (long)pt0 * src_pstride + kq * LK + l16;
+    // groups of G k-steps (4 G input rows); the next group's W fragments are in flight (L2 latency) behind this group's MFMAs
+    constexpr int G = 4;
+    static_assert(KD % (4 * G) == 0, "KD in whole groups");
+    float an[G][NRT];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) an[g][i] = wl[(long)(4 * g) * ROWS + i * WR * 16];
+    for (int jj = 0; jj < KD; jj += 4 * G) {
+        float ac[G][NRT], bv[G][NPT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) ac[g][i] = an[g][i];
+        if (jj + 4 * G < KD) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) an[g][i] = wl[(long)(jj + 4 * G + 4 * g) * ROWS + i * WR * 16];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) bv[g][j] = sl[(jj + 4 * g) * LK + j * WP * src_pstride];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < NRT; ++i)
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int D, int PP>
+__global__ __launch_bounds__(256) void lfa_stage_mfma_kernel(const LfaArgs a)
+{
+    constexpr int H = D / 2;
+    constexpr int P = (256 / D) * PP;                  // points per workgroup
+    __shared__ __attribute__((aligned(16))) float fcat[P][D][LK];
+    __shared__ __attribute__((aligned(16))) float fx1[P][H][LK];
+    __shared__ float pe[P][10][LK];
+    __shared__ int nidx[P][LK];
+    __shared__ float aggv[P][D];
+
+    const int tid = threadIdx.x;
+    const int slot = tid / D, c = tid - slot * D;
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y;
+    const int n = a.n;
+    const float slope = a.slope;
+    int pidx[PP];
+    bool live[PP];
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int raw = (int)blockIdx.x * P + slot * PP + pp;
+        live[pp] = raw < n;
+        pidx[pp] = min(raw, n - 1);
+    }
+
+    // 1. relative position encoding (as lfa_stage_kernel)
+    if (c < LK) {
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const int p = slot * PP + pp, i = pidx[pp];
+            int jn = a.idx[((long)b * n + i) * LK + c];
+            jn = min(max(jn, 0), n - 1);
+            const float* pi = a.xyz + ((long)b * n + i) * 3;
+            const float* pj = a.xyz + ((long)b * n + jn) * 3;
+            const float ax = pi[0], ay = pi[1], az = pi[2];
+            const float bx = pj[0], by = pj[1], bz = pj[2];
+            const float rx = __fsub_rn(ax, bx), ry = __fsub_rn(ay, by), rz = __fsub_rn(az, bz);
+            float s = __fmul_rn(rx, rx);
+            s = __fadd_rn(s, __fmul_rn(ry, ry));
+            s = __fadd_rn(s, __fmul_rn(rz, rz));
+            pe[p][0][c] = __fsqrt_rn(s);
+            pe[p][1][c] = rx; pe[p][2][c] = ry; pe[p][3][c] = rz;
+            pe[p][4][c] = ax; pe[p][5][c] = ay; pe[p][6][c] = az;
+            pe[p][7][c] = bx; pe[p][8][c] = by; pe[p][9][c] = bz;
+            nidx[p][c] = jn;
+        }
+    }
+    __syncthreads();
+
+    // 2. mlp1 on the encoding and the neighbour gather (as lfa_stage_kernel)
+    {
+        const int j = c % H, kb = (c / H) * 8;
+        float w[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) w[q] = a.w1t[q * H + j];
+        const float sc = a.s1[j], sh = a.b1[j];
+        const float* frow = a.feat + ((long)b * H + j) * n;
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const int p = slot * PP + pp;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = kb + kk;
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) v = fmaf(w[q], pe[p][q][k], v);
+                v = lrelu(fmaf(v, sc, sh), slope);
+                if (a.w2t) fx1[p][j][k] = v;
+                else fcat[p][H + j][k] = v;
+                fcat[p][j][k] = frow[nidx[p][k]];
+            }
+        }
+    }
+    __syncthreads();
+
+    // 2b. second stage: mlp2 on the encoded positions, tiles of (16 channels of H) x (point)
+    if (a.w2t) {
+        constexpr int RT = H / 16, WR = RT < 4 ? RT : 4, WP = 4 / WR, NRT = RT / WR, NPT = P / WP;
+        static_assert(RT >= 1 && NRT * WR == RT && NPT * WP == P, "mlp2 tiling");
+        const int wr = wave % WR, wp = wave / WR;
+        lfa_f32x4 acc[NRT][NPT];
+        lfa_tiles<H, H, NRT, NPT, WR, WP>(a.w2t, &fx1[0][0][0], H * LK, wr, wp, l16, kq, acc);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int c0 = (wr + WR * i) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = c0 + 4 * r + kq;
+                const float sc = a.s2[ch], sh = a.b2[ch];
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) fcat[wp + WP * j][H + ch][l16] = lrelu(fmaf(acc[i][j][r], sc, sh), slope);
+            }
+        }
+        __syncthreads();
+    }
+
+    // 3 + 4. attention logits, softmax over the 16 neighbours (= the 16 lanes of a row), feature * score, sum
+    {
+        constexpr int RT = D / 16, WR = RT < 4 ? RT : 4, WP = 4 / WR, NRT = RT / WR, NPT = P / WP;
+        static_assert(NRT * WR == RT && NPT * WP == P, "attention tiling");
+        const int wr = wave % WR, wp = wave / WR;
+        lfa_f32x4 acc[NRT][NPT];
+        lfa_tiles<D, D, NRT, NPT, WR, WP>(a.wft, &fcat[0][0][0], D * LK, wr, wp, l16, kq, acc);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int c0 = (wr + WR * i) * 16;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int p = wp + WP * j;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = c0 + 4 * r + kq;
+                    const float t = acc[i][j][r];
+                    const float mx = row16_max(t);
+                    const float e = __expf(t - mx);
+                    const float den = row16_sum(e, l16);
+                    const float num = row16_sum(fcat[p][ch][l16] * (e * (1.0f / den)), l16);
+                    if (l16 == 0) aggv[p][ch] = num;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // 5. mlp on the pooled feature (as lfa_stage_kernel)
+    const int OUT = a.OUT;
+    if (c < OUT) {
+        float o[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) o[pp] = 0.f;
+#pragma unroll 8
+        for (int jj = 0; jj < D; ++jj) {
+            const float w = a.wmt[jj * OUT + c];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) o[pp] = fmaf(w, aggv[slot * PP + pp][jj], o[pp]);
+        }
+        const float sm = a.sm[c], bm = a.bm[c];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp)
+            if (live[pp]) a.out[((long)b * OUT + c) * n + pidx[pp]] = lrelu(fmaf(o[pp], sm, bm), slope);
+    }
+}
+
 } // namespace
 
 extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const float* feat, const float* w1t, const float* s1, const float* b1,
@@ -223,6 +453,23 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     // points per thread group: 1.  GDM_LFA_PP=2 (development) lets a thread walk two points at D = 128 / 256 so that every weight load
     // feeds two points: measured SLOWER (71 -> 82 us and 75 -> 120 us per block of two stages at batch 16): the deep levels have
     // 2048 / 512 points in all, and halving the workgroups costs more than the shared loads save
+    // default: the MFMA form from D = 128 up (GDM_LFA_MFMA=0: the FMA form everywhere; = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1:
+    // one point per thread group in the MFMA form -- development switches)
+    static const int mf_env = getenv("GDM_LFA_MFMA") ? atoi(getenv("GDM_LFA_MFMA")) : 1;
+    static const int mfpp_env = getenv("GDM_LFA_MFMA_PP") ? atoi(getenv("GDM_LFA_MFMA_PP")) : 0;
+    if (mf_env && D >= (mf_env > 1 ? mf_env : 128)) {
+        const int pp = mfpp_env == 1 ? 1 : 2;
+        const int P = (256 / D) * pp;
+        dim3 g(gdm_cdiv(n, P), B);
+#define GDM_LFA_MF(DD) do { if (pp == 1) hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 1>), g, dim3(256), 0, s, a); \
+                            else hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 2>), g, dim3(256), 0, s, a); } while (0)
+        if (D == 32) GDM_LFA_MF(32);
+        else if (D == 64) GDM_LFA_MF(64);
+        else if (D == 128) GDM_LFA_MF(128);
+        else GDM_LFA_MF(256);
+#undef GDM_LFA_MF
+        return gdm_launch_status("lfa_stage_mfma_kernel");
+    }
     static const int pp_env = getenv("GDM_LFA_PP") ? atoi(getenv("GDM_LFA_PP")) : 0;
     const int PP = pp_env == 2 ? 2 : 1;
     const int P = (256 / D) * PP;
