@@ -343,13 +343,14 @@ constexpr int MF_NPH = GDM_CONV_NPH;
 constexpr int MF_WPIX = 16 * MF_NPH;                  // pixels per wave
 constexpr int MF_WAVES = CV_PIX / MF_WPIX;
 constexpr int MF_THREADS = MF_WAVES * 64;
-constexpr int MF_STAGE = 4096 / MF_THREADS;           // 16-byte chunks of a weight panel per thread
 constexpr int MF_TSTRIDE = 132;                       // floats per pixel row of a wave's output tile in LDS (128 + 4: conflict-free reads)
 constexpr int MF_SMEM = 2 * CV_PANEL > CV_PIX * MF_TSTRIDE * 4 ? 2 * CV_PANEL : CV_PIX * MF_TSTRIDE * 4;
 
 // NCB = 16-channel output blocks per workgroup: 8 (128 channels) or 4 (64 channels: twice the workgroups for the layers whose 128-channel
 // tiling leaves half the chip idle -- layer1-3 of the trunk at batch 16 -- and no zero-padded weight rows for 64-channel layers)
-template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8, int NCB = 8>
+// WV = waves per workgroup: 8 (256 pixels), or 4 (128 pixels: the 128 -> 128 layers at 32 x 32 have 128 workgroups of the 256-pixel, 64-channel
+// tiling on 256 CUs -- half tiles put one on every CU)
+template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8, int NCB = 8, int WV = MF_WAVES>
 __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const int hw = H * W;
     const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
     const unsigned bx = co_fastest ? blockIdx.y : blockIdx.x, by = co_fastest ? blockIdx.x : blockIdx.y;
-    const long pix0 = (long)bx * CV_PIX + wave * MF_WPIX;           // this wave's first pixel
+    const long pix0 = (long)bx * (WV * MF_WPIX) + wave * MF_WPIX;           // this wave's first pixel
     const int co0 = tile_co0 ? tile_co0[bx] : by * (NCB * 16);
     const long pc = min(pix0, ptot - MF_WPIX);
     const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
@@ -412,14 +413,15 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         }
     };
     // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
-    constexpr int HS = (NCB * 512 / MF_THREADS) / 2;
+    constexpr int THREADS = WV * 64, WGPIX = WV * MF_WPIX;
+    constexpr int HS = (NCB * 512 / THREADS) / 2;
     u32x4 stage[HS];
-    const unsigned char* wpk_b = wpk + (wbstride ? ((long)bx * CV_PIX / hw) * wbstride : 0);
+    const unsigned char* wpk_b = wpk + (wbstride ? ((long)bx * WGPIX / hw) * wbstride : 0);
     auto stage_load = [&](int it, int half) {
         const unsigned char* src = wpk_b + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
-            const int g = (half * HS + i) * MF_THREADS + tid;
+            const int g = (half * HS + i) * THREADS + tid;
             stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
         }
     };
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         unsigned char* base = smem + buf * PANEL;
 #pragma unroll
         for (int i = 0; i < HS; ++i) {
-            const int g = (half * HS + i) * MF_THREADS + tid;
+            const int g = (half * HS + i) * THREADS + tid;
             *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
         }
     };
@@ -726,6 +728,27 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
             AT4(0, false, 4); AT4(1, false, 4); AT4(0, true, 4); AT4(1, true, 4);
             AT4(0, false, 8); AT4(1, false, 8); AT4(0, true, 8); AT4(1, true, 8);
             attr4 = true;
+        }
+        // still fewer workgroups than CUs (128 -> 128 at 32 x 32, batch 16: 64 x 2): 128-pixel workgroups of four waves
+        static int half_env = -1;
+        if (half_env < 0) {
+            const char* e = getenv("GDM_CONV_HALF_TILES");
+            half_env = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (half_env && Cin != 64 && (long)grid4.x * grid4.y < 256 && ptot % (CV_PIX / 2) == 0) {
+            const dim3 grid4h(gdm_cdiv(ptot, CV_PIX / 2), grid4.y);
+            static bool attr4h = false;
+#define CV4H(A, R) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, 8, 4, MF_WAVES / 2>), grid4h, dim3(CONV_THREADS / 2), SMEM4, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
+#define AT4H(A, R) (void)hipFuncSetAttribute((const void*)CONV_KERNEL<A, R, 9, false, 8, 4, MF_WAVES / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4)
+            if (!attr4h) {
+                AT4H(0, false); AT4H(1, false); AT4H(0, true); AT4H(1, true);
+                attr4h = true;
+            }
+            if (act == 0) { if (res) CV4H(0, true); else CV4H(0, false); }
+            else { if (res) CV4H(1, true); else CV4H(1, false); }
+#undef CV4H
+#undef AT4H
+            return gdm_launch_status("conv3x3_bf16x3_kernel (64-channel tiles, 128 pixels)");
         }
         if (Cin == 64) {
             if (act == 0) { if (res) CV4(0, true, 4); else CV4(0, false, 4); }
