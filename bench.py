@@ -164,6 +164,25 @@ def kernel_rooflines(torch, dev, B, N):
     def traffic(*patterns):
         vals = [pmc[p]["bytes_per_launch"] for p in patterns if p in pmc]
         return sum(vals) if len(vals) == len(patterns) else None
+    # (0) what the matrix pipe sustains on this box: register-only MFMA loop, one 8-wave workgroup per CU, ~0.25 ms per launch
+    #     (the duration of the convolution launches below), back-to-back like them
+    probe = probe_chain3 = None
+    try:
+        sink = torch.zeros(4, device=dev)
+        blocks, iters = 256, 3000
+        pr = lambda: _lib.check(L.gdm_mfma_probe_hip(blocks, iters, 1, sink.data_ptr(), ops._stream()), "probe")
+        for _ in range(3):
+            pr()
+        pms = timed_launches(pr, n, torch)
+        probe = blocks * 8 * iters * 8 * 16384.0 / pms / 1e9
+        pr3 = lambda: _lib.check(L.gdm_mfma_probe_hip(blocks, iters, 3, sink.data_ptr(), ops._stream()), "probe")
+        pr3()
+        probe_chain3 = blocks * 8 * iters * 8 * 16384.0 / timed_launches(pr3, n, torch) / 1e9
+    except Exception:                                           # noqa: BLE001
+        probe = None
+
+    def vs_probe(tflops):
+        return None if not probe else round(tflops / probe, 4)
     # (1) trunk 3x3 convolution 512 -> 512 at 32 x 32 (ResNet-18 layer4, extractors.py:36-58), kernel alone on packed operands
     Cin = Cout = 512
     H = W = 32
@@ -183,6 +202,8 @@ def kernel_rooflines(torch, dev, B, N):
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
                 "traffic": traffic("conv_mfma16_kernel<0, false, 9, false, 8, 8>"),
+                "mfma_probe_tflops": None if not probe else round(probe, 1), "frac_of_probe": vs_probe(3 * fl / ms / 1e9),
+                "mfma_probe_chain3_tflops": None if not probe_chain3 else round(probe_chain3, 1),
                 "work": "2*9*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * H * W)})
     # (2) neighbour pyramid, K = 16 searches (knn_wave_kernel): pair evaluations per second against the vector-ALU bound
     batch = synthetic.make_batch(seed=100, batch=B, n_points=N)
@@ -233,6 +254,7 @@ def kernel_rooflines(torch, dev, B, N):
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
                 "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 8>"),
+                "mfma_probe_tflops": None if not probe else round(probe, 1), "frac_of_probe": vs_probe(3 * fl / ms / 1e9),
                 "work": "2*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * 32 * 32)})
     # (5) the last image stage at the sampled pixels (up_3 + final at `choose`): replaces a 64 -> 64 3x3 convolution and a 1x1 + log-softmax
     # over the whole 256^2 map (361 + 130 us) -- priced against reading the 128^2 source map once and writing the N sampled columns

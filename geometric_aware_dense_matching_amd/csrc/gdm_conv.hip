@@ -339,6 +339,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #ifndef GDM_CONV_NPH
 #define GDM_CONV_NPH 2
 #endif
+// 1: the MFMAs of a unit are issued product-major (no MFMA directly behind the one whose accumulator it reads); 0: accumulator-major.
+// Measured equal (512 -> 512: 191 vs 188 us on two boxes; the register-only probe gdm_mfma_probe_hip sustains 2.25 PF/s with independent and
+// 2.40 PF/s with back-to-back dependent MFMAs at two waves per SIMD): dependent issue is not what idles the pipe.  0 ships.
+#ifndef GDM_CONV_MFMA_ORDER
+#define GDM_CONV_MFMA_ORDER 0
+#endif
 constexpr int MF_NPH = GDM_CONV_NPH;
 constexpr int MF_WPIX = 16 * MF_NPH;                  // pixels per wave
 constexpr int MF_WAVES = CV_PIX / MF_WPIX;
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         for (int u = 0; u < NU; ++u) {
             const int S = u / NPR, pr = u % NPR, slot = u % (PF + 1);
             if (u + PF < NU) frag_load(u + PF);
+#if GDM_CONV_MFMA_ORDER == 0
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[S][ph]);
@@ -490,6 +497,20 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                     acc[ph][2 * pr + j] = c;
                 }
             }
+#else
+            // product-major: the unit's 2 NPH accumulators take hi.lo, then lo.hi, then hi.hi -- the same three terms in the same order per
+            // accumulator (bit-identical sums), but an MFMA never waits for its predecessor's result (2 NPH - 1 others in between)
+#pragma unroll
+            for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16x8 av = __builtin_bit_cast(bf16x8, prod == 1 ? alo[S][ph] : ahi[S][ph]);
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, prod == 0 ? fl[slot][j] : fh[slot][j]);
+                        acc[ph][2 * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[ph][2 * pr + j], 0, 0, 0);
+                    }
+#endif
             if (pr == NPR - 1 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
             if (u == NU / 2 && more) {                              // the other buffer's readers finished at this panel's barrier
                 stage_store((it + 1) & 1, 0);
@@ -602,6 +623,48 @@ constexpr int CONV_THREADS = CV_THREADS, CONV_WPIX = 32, CONV_SMEM = 2 * CV_PANE
 #endif
 
 } // namespace
+
+// Measurement aid (bench.py): what the matrix pipe sustains on THIS chip with nothing else in the way -- every wave issues `iters` x 8
+// independent v_mfma_f32_16x16x32_bf16 on registers (no LDS, no memory), eight waves per CU like the convolution kernel.  The chip lowers
+// its clock under such a load (MI355X_MICROARCH.md, DVFS), so this -- not the 2.5 PFLOP/s of the data sheet clock -- is the ceiling an
+// MFMA-bound kernel can be compared with on the box it runs on.
+namespace {
+template <int CHAIN>
+__global__ __launch_bounds__(512) void mfma_probe_kernel(int iters, float* __restrict__ sink)
+{
+    typedef __attribute__((ext_vector_type(8))) __bf16 pb_bf16x8;
+    typedef __attribute__((ext_vector_type(4))) float pb_f32x4;
+    const int lane = threadIdx.x & 63;
+    pb_f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = pb_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned seed = 0x3f803f80u + (unsigned)lane;             // bf16 pairs near 1.0
+    u32x4 av = {seed, seed ^ 1u, seed ^ 2u, seed ^ 3u}, bv = {seed ^ 4u, seed ^ 5u, seed ^ 6u, seed ^ 7u};
+    const pb_bf16x8 a = __builtin_bit_cast(pb_bf16x8, av), b = __builtin_bit_cast(pb_bf16x8, bv);
+    // CHAIN consecutive MFMAs into the same accumulator before moving to the next one (1: every MFMA independent of its predecessor;
+    // 3: the hi.lo / lo.hi / hi.hi triple of a split-bf16 product issued back to back)
+    for (int it = 0; it < iters; it += CHAIN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < CHAIN; ++c) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (t == 12345.678f) sink[0] = t;                               // keeps the loop alive; never true
+}
+} // namespace
+
+// flops of one launch = blocks * 8 waves * iters * 8 MFMAs * 16*16*32*2
+extern "C" int gdm_mfma_probe_hip(int blocks, int iters, int chain, float* sink, void* stream)
+{
+    GDM_CHECK_ARG(blocks >= 1 && blocks <= 65535 && iters >= 3 && iters % 3 == 0 && (chain == 1 || chain == 3) && sink,
+                  "gdm_mfma_probe_hip: bad arguments (iters a multiple of 3, chain 1 or 3)");
+    if (chain == 3) hipLaunchKernelGGL(mfma_probe_kernel<3>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, iters, sink);
+    else hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, iters, sink);
+    return gdm_launch_status("mfma_probe_kernel");
+}
 
 static bool cin_ok(int Cin) { return Cin == 64 || (Cin >= 128 && Cin % 128 == 0); }
 

@@ -510,6 +510,10 @@ int gdm_wgrad_pack_go_hip(const float* go, int B, int Cout, int H, int W, void* 
  * gdm_conv1x1_packed_wb_hip(xpk, gpk, n*CoutP*512, parts, 128*n, Cout, 1, Cin, out f32[parts, Cout, Cin], stream) (Cin % 256 == 0). */
 size_t gdm_wgrad_x1_bytes(int B, int Cin, int P);
 int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void* out, void* stream);
+/* Measurement aid: `blocks` workgroups of 8 waves, each wave `iters` x 8 independent v_mfma_f32_16x16x32_bf16 on registers (no memory):
+ * the rate the matrix pipe sustains on this chip at the clock it holds under that load.  flops = blocks*8*iters*8*16384.  chain = 1: no
+ * MFMA depends on its predecessor; chain = 3: three consecutive MFMAs into one accumulator (a split-bf16 product issued back to back). */
+int gdm_mfma_probe_hip(int blocks, int iters, int chain, float* sink, void* stream);
 /* Small-channel form with no re-layout pass (HBM-bound; the 1x1 layers of the 32 / 64-channel full-resolution stages and of the point
  * branch under training): partial[s][co][ci] = sum over the s-th of nsplit slices of the B*P/32 pixel steps of go[b,co,p] * x[b,ci,p]
  * (rows of P floats, batch strides in elements, P % 32 == 0, split-bf16 MFMA); bias_partial[s][co] (optional) = the row sums of go.
