@@ -342,6 +342,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // 1: the MFMAs of a unit are issued product-major (no MFMA directly behind the one whose accumulator it reads); 0: accumulator-major.
 // Measured equal (512 -> 512: 191 vs 188 us on two boxes; the register-only probe gdm_mfma_probe_hip sustains 2.25 PF/s with independent and
 // 2.40 PF/s with back-to-back dependent MFMAs at two waves per SIMD): dependent issue is not what idles the pipe.  0 ships.
+// k-steps (of the 4 of a 128-channel panel) whose operand reload is deferred to the top of the next panel
+#ifndef GDM_CONV16_LATE
+#define GDM_CONV16_LATE 1
+#endif
 #ifndef GDM_CONV_MFMA_ORDER
 #define GDM_CONV_MFMA_ORDER 0
 #endif
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[ph][cb][i] = 0.f;
 
-    constexpr int LATE = 1;                                         // k-steps whose reload is deferred to the next iteration's top
+    constexpr int LATE = GDM_CONV16_LATE < NS ? GDM_CONV16_LATE : NS;                           // k-steps whose reload is deferred to the next iteration's top
     stage_load(0, 0);
     stage_store(0, 0);
     stage_load(0, 1);
@@ -654,7 +658,51 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(int iters, float* __res
     for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (t == 12345.678f) sink[0] = t;                               // keeps the loop alive; never true
 }
+// The same with the B operands re-read from LDS at the convolution kernel's ratio: per unit of 12 MFMAs (four accumulators x the three
+// split products) four ds_read_b128 of 64 consecutive 16-byte chunks (conflict-free); RPU = reads per unit (4 = the kernel's, 2, 1).
+template <int RPU>
+__global__ __launch_bounds__(512) void mfma_probe_lds_kernel(int iters, float* __restrict__ sink)
+{
+    typedef __attribute__((ext_vector_type(8))) __bf16 pb_bf16x8;
+    typedef __attribute__((ext_vector_type(4))) float pb_f32x4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl[];          // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += 512) reinterpret_cast<u32x4*>(pl)[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)i};
+    __syncthreads();
+    pb_f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = pb_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned seed = 0x3f803f80u + (unsigned)lane;
+    u32x4 a0 = {seed, seed ^ 1u, seed ^ 2u, seed ^ 3u}, a1 = {seed ^ 4u, seed ^ 5u, seed ^ 6u, seed ^ 7u};
+    u32x4 f[4] = {a0, a1, a0, a1};
+    int off = lane * 16;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < RPU; ++r) f[r] = *reinterpret_cast<const u32x4*>(pl + ((off + r * 1024) & 0xffff));
+        off += 4096;
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pb_bf16x8, prod == 1 ? a1 : a0),
+                                                                 __builtin_bit_cast(pb_bf16x8, f[(i + prod) & 3]), acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (t == 12345.678f) sink[0] = t;
+}
 } // namespace
+
+// LDS-fed probe: flops of one launch = blocks * 8 waves * iters * 12 MFMAs * 16384; rpu = ds_read_b128 per 12 MFMAs (1, 2 or 4)
+extern "C" int gdm_mfma_probe_lds_hip(int blocks, int iters, int rpu, float* sink, void* stream)
+{
+    GDM_CHECK_ARG(blocks >= 1 && blocks <= 65535 && iters >= 1 && (rpu == 1 || rpu == 2 || rpu == 4) && sink, "gdm_mfma_probe_lds_hip: bad arguments");
+    if (rpu == 4) hipLaunchKernelGGL(mfma_probe_lds_kernel<4>, dim3(blocks), dim3(512), 65536, (hipStream_t)stream, iters, sink);
+    else if (rpu == 2) hipLaunchKernelGGL(mfma_probe_lds_kernel<2>, dim3(blocks), dim3(512), 65536, (hipStream_t)stream, iters, sink);
+    else hipLaunchKernelGGL(mfma_probe_lds_kernel<1>, dim3(blocks), dim3(512), 65536, (hipStream_t)stream, iters, sink);
+    return gdm_launch_status("mfma_probe_lds_kernel");
+}
 
 // flops of one launch = blocks * 8 waves * iters * 8 MFMAs * 16*16*32*2
 extern "C" int gdm_mfma_probe_hip(int blocks, int iters, int chain, float* sink, void* stream)

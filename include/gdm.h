@@ -514,6 +514,9 @@ int gdm_wgrad_pack_x1_hip(const float* x, int B, int Cin, int P, void* out, void
  * the rate the matrix pipe sustains on this chip at the clock it holds under that load.  flops = blocks*8*iters*8*16384.  chain = 1: no
  * MFMA depends on its predecessor; chain = 3: three consecutive MFMAs into one accumulator (a split-bf16 product issued back to back). */
 int gdm_mfma_probe_hip(int blocks, int iters, int chain, float* sink, void* stream);
+/* The same loop with the B operands re-read from LDS: rpu (1, 2, 4) ds_read_b128 per 12 MFMAs (4 = the convolution kernel's ratio).
+ * flops = blocks*8*iters*12*16384. */
+int gdm_mfma_probe_lds_hip(int blocks, int iters, int rpu, float* sink, void* stream);
 /* Small-channel form with no re-layout pass (HBM-bound; the 1x1 layers of the 32 / 64-channel full-resolution stages and of the point
  * branch under training): partial[s][co][ci] = sum over the s-th of nsplit slices of the B*P/32 pixel steps of go[b,co,p] * x[b,ci,p]
  * (rows of P floats, batch strides in elements, P % 32 == 0, split-bf16 MFMA); bias_partial[s][co] (optional) = the row sums of go.
