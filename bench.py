@@ -382,7 +382,7 @@ def heavy_extras(torch, dev, args, model, N, M):
         torch.backends.cudnn.benchmark = False                        # MIOpen default algorithms: find mode over ~100 backward shapes takes minutes
         try:
             tm = GeoMatch(make_model_cfg(n_mesh_node=Mt, num_points=Nt), 1, model_points=synthetic.make_model_points(1, Mt)).to(dev).train()
-            opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
+            opt = torch.optim.Adam(tm.parameters(), lr=1e-4, fused=settings.USE_FUSED_ADAM)      # as train_lm.py builds it
             ds = train_lm.SyntheticCrops(Bt, Nt, Mt, seed=0)
             cu = train_lm.to_device(torch.utils.data.default_collate([ds[i] for i in range(Bt)]), dev)
 
