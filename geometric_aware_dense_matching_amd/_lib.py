@@ -206,6 +206,8 @@ def build_record():
     except OSError:
         rec["loaded_lib_sha256_16"] = None
     rec.pop("up_to_date", None)
+    if rec.get("lib_sha256_16") is not None:                    # the record describes ANOTHER build (e.g. `make` run by hand afterwards)
+        rec["record_matches_loaded_lib"] = rec["lib_sha256_16"] == rec["loaded_lib_sha256_16"]
     return rec
 
 
