@@ -453,12 +453,13 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     // points per thread group: 1.  GDM_LFA_PP=2 (development) lets a thread walk two points at D = 128 / 256 so that every weight load
     // feeds two points: measured SLOWER (71 -> 82 us and 75 -> 120 us per block of two stages at batch 16): the deep levels have
     // 2048 / 512 points in all, and halving the workgroups costs more than the shared loads save
-    // default: the MFMA form from D = 128 up (GDM_LFA_MFMA=0: the FMA form everywhere; = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1:
-    // one point per thread group in the MFMA form -- development switches)
+    // default: the MFMA form from D = 64 up, one point per thread group at D = 64 and two above (GDM_LFA_MFMA=0: the FMA form everywhere;
+    // = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1 / 2: points per thread group in the MFMA form -- development switches).
+    // In the step (hipGraph replay, two boxes): D >= 128 only 3.989 / 3.972 ms, D >= 64 3.966 / 3.962 ms; D = 32 stays on the FMA form
     static const int mf_env = getenv("GDM_LFA_MFMA") ? atoi(getenv("GDM_LFA_MFMA")) : 1;
     static const int mfpp_env = getenv("GDM_LFA_MFMA_PP") ? atoi(getenv("GDM_LFA_MFMA_PP")) : 0;
-    if (mf_env && D >= (mf_env > 1 ? mf_env : 128)) {
-        const int pp = mfpp_env == 1 ? 1 : 2;
+    if (mf_env && D >= (mf_env > 1 ? mf_env : 64)) {
+        const int pp = mfpp_env ? (mfpp_env == 1 ? 1 : 2) : (D <= 64 ? 1 : 2);
         const int P = (256 / D) * pp;
         dim3 g(gdm_cdiv(n, P), B);
 #define GDM_LFA_MF(DD) do { if (pp == 1) hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 1>), g, dim3(256), 0, s, a); \
