@@ -212,36 +212,30 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
 // v_mfma_f32_16x16x4_f32 (exact fp32 products).  In the FMA form above every thread reads the whole d x 16 block of its point from
 // LDS (four 16-byte broadcast reads per 16 FMAs): the stage is bound by LDS issue, 35-63 us per launch for ~1 GFLOP.  Here a tile is
 // 16 channels x the 16 neighbours of one point:
-//   A fragment (W^T [in][out]):  lane l = output channel c0 + 4 (l & 3) + ((l & 15) >> 2), input row j + (l >> 4)     (global, 64-byte runs)
-//   B fragment (block in LDS):   lane l = neighbour l & 15, input row j + (l >> 4)                                     (256 contiguous bytes)
-//   accumulator:                 lane l = neighbour l & 15, register r = output channel c0 + 4 r + (l >> 4)
-// so the softmax over the neighbours and the weighted sum are reductions over the 16 lanes of a DPP row, and the feature the weighted
-// sum needs -- fcat[c0 + 4 r + (l >> 4)][l & 15] -- is one conflict-free LDS read (the rows of W are permuted for exactly that).
+//   A fragment (block in LDS):   lane l = neighbour l & 15, input row j + (l >> 4)                     (256 contiguous bytes, conflict-free)
+//   B fragment (W^T [in][out]):  lane l = output channel c0 + (l & 15), input row j + (l >> 4)         (global, 64-byte runs)
+//   accumulator:                 lane l = output channel c0 + (l & 15), register r = neighbour 4 (l >> 4) + r
+// so a lane holds four neighbours of ONE channel: the softmax over the 16 neighbours is three in-lane steps plus two cross-row
+// exchanges (lanes l, l ^ 16, l ^ 32, l ^ 48), and the feature the weighted sum needs -- fcat[c][4 (l >> 4) .. + 4] -- is one
+// conflict-free 16-byte LDS read; mlp2's output goes back to the block as one 16-byte LDS write per lane.
 // A workgroup owns P = 512 / D points (phases 1, 2 and 5 as above with two points per thread group); its 4 waves tile (channel tiles) x
 // (points).  One LDS dword read + one global dword load per 1024 products instead of 64 bytes of LDS per 16.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float lfa_f32x4;
 
-__device__ __forceinline__ float row16_max(float v)
+// all-reduce over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (same l & 15), in one fixed order for every lane
+__device__ __forceinline__ float quadrow_max(float v)
 {
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));   // row_mirror
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
-// sum over the 16 lanes of a row in ONE fixed order for every lane: ((quad pairs) + other half of the 8) + other 8; the operand order of
-// each add is made lane-independent (lower lanes' partial first), so all 16 lanes hold bit-identical sums
-__device__ __forceinline__ float row16_sum(float v, int l16)
+__device__ __forceinline__ float quadrow_sum(float v, int kq)
 {
-    float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-    v = (l16 & 1) ? o + v : v + o;
-    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-    v = (l16 & 2) ? o + v : v + o;
-    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-    v = (l16 & 4) ? o + v : v + o;
-    o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-    v = (l16 & 8) ? o + v : v + o;
+    float o = __shfl_xor(v, 16);
+    v = (kq & 1) ? o + v : v + o;
+    o = __shfl_xor(v, 32);
+    v = (kq & 2) ? o + v : v + o;
     return v;
 }
 
@@ -250,14 +244,13 @@ template <int ROWS, int KD, int NRT, int NPT, int WR, int WP>
 __device__ __forceinline__ void lfa_tiles(const float* __restrict__ wt, const float* src, int src_pstride, int rt0, int pt0, int l16, int kq,
                                           lfa_f32x4 (&acc)[NRT][NPT])
 {
-    const int perm = 4 * (l16 & 3) + (l16 >> 2);
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
 #pragma unroll
         for (int j = 0; j < NPT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    const float* wl = wt + (long)kq * ROWS + rt0 * 16 + perm;
+    const float* wl = wt + (long)kq * ROWS + rt0 * 16 + l16;
     const float* sl = src + (long)pt0 * src_pstride + kq * LK + l16;
     // groups of G k-steps (4 G input rows); the next group's W fragments are in flight (L2 latency) behind this group's MFMAs
     constexpr int G = 4;
@@ -288,7 +281,7 @@ __device__ __forceinline__ void lfa_tiles(const float* __restrict__ wt, const fl
 #pragma unroll
             for (int i = 0; i < NRT; ++i)
 #pragma unroll
-                for (int j = 0; j < NPT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NPT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[g][j], ac[g][i], acc[i][j], 0, 0, 0);
     }
 }
 
@@ -377,13 +370,14 @@ __global__ __launch_bounds__(256) void lfa_stage_mfma_kernel(const LfaArgs a)
         lfa_tiles<H, H, NRT, NPT, WR, WP>(a.w2t, &fx1[0][0][0], H * LK, wr, wp, l16, kq, acc);
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-            const int c0 = (wr + WR * i) * 16;
+            const int ch = (wr + WR * i) * 16 + l16;
+            const float sc = a.s2[ch], sh = a.b2[ch];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = c0 + 4 * r + kq;
-                const float sc = a.s2[ch], sh = a.b2[ch];
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) fcat[wp + WP * j][H + ch][l16] = lrelu(fmaf(acc[i][j][r], sc, sh), slope);
+            for (int j = 0; j < NPT; ++j) {
+                float4 o;
+                o.x = lrelu(fmaf(acc[i][j][0], sc, sh), slope); o.y = lrelu(fmaf(acc[i][j][1], sc, sh), slope);
+                o.z = lrelu(fmaf(acc[i][j][2], sc, sh), slope); o.w = lrelu(fmaf(acc[i][j][3], sc, sh), slope);
+                *reinterpret_cast<float4*>(&fcat[wp + WP * j][H + ch][4 * kq]) = o;
             }
         }
         __syncthreads();
@@ -398,20 +392,18 @@ __global__ __launch_bounds__(256) void lfa_stage_mfma_kernel(const LfaArgs a)
         lfa_tiles<D, D, NRT, NPT, WR, WP>(a.wft, &fcat[0][0][0], D * LK, wr, wp, l16, kq, acc);
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-            const int c0 = (wr + WR * i) * 16;
+            const int ch = (wr + WR * i) * 16 + l16;
 #pragma unroll
             for (int j = 0; j < NPT; ++j) {
                 const int p = wp + WP * j;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = c0 + 4 * r + kq;
-                    const float t = acc[i][j][r];
-                    const float mx = row16_max(t);
-                    const float e = __expf(t - mx);
-                    const float den = row16_sum(e, l16);
-                    const float num = row16_sum(fcat[p][ch][l16] * (e * (1.0f / den)), l16);
-                    if (l16 == 0) aggv[p][ch] = num;
-                }
+                const lfa_f32x4 t = acc[i][j];
+                const float mx = quadrow_max(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
+                const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
+                const float den = quadrow_sum((e0 + e1) + (e2 + e3), kq);
+                const float4 f = *reinterpret_cast<const float4*>(&fcat[p][ch][4 * kq]);
+                const float rden = 1.0f / den;
+                const float num = quadrow_sum((f.x * (e0 * rden) + f.y * (e1 * rden)) + (f.z * (e2 * rden) + f.w * (e3 * rden)), kq);
+                if (kq == 0) aggv[p][ch] = num;
             }
         }
     }
@@ -453,12 +445,13 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     // points per thread group: 1.  GDM_LFA_PP=2 (development) lets a thread walk two points at D = 128 / 256 so that every weight load
     // feeds two points: measured SLOWER (71 -> 82 us and 75 -> 120 us per block of two stages at batch 16): the deep levels have
     // 2048 / 512 points in all, and halving the workgroups costs more than the shared loads save
-    // default: the MFMA form from D = 64 up, one point per thread group at D = 64 and two above (GDM_LFA_MFMA=0: the FMA form everywhere;
-    // = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1 / 2: points per thread group in the MFMA form -- development switches).
-    // In the step (hipGraph replay, two boxes): D >= 128 only 3.989 / 3.972 ms, D >= 64 3.966 / 3.962 ms; D = 32 stays on the FMA form
+    // default: the MFMA form at every level, one point per thread group at D = 32 / 64 and two above (GDM_LFA_MFMA=0: the FMA form
+    // everywhere; = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1 / 2: points per thread group in the MFMA form -- development
+    // switches).  Per block of two stages at batch 16 (tools/bench_lfa.py, FMA -> MFMA): 109 -> 96, 82 -> 69, 70 -> 60, 73 -> 60 us;
+    // whole step (eager / hipGraph replay, one box): FMA at D = 32 only 3.830 / 3.957 ms, MFMA everywhere 3.807 / 3.942 ms
     static const int mf_env = getenv("GDM_LFA_MFMA") ? atoi(getenv("GDM_LFA_MFMA")) : 1;
     static const int mfpp_env = getenv("GDM_LFA_MFMA_PP") ? atoi(getenv("GDM_LFA_MFMA_PP")) : 0;
-    if (mf_env && D >= (mf_env > 1 ? mf_env : 64)) {
+    if (mf_env && D >= (mf_env > 1 ? mf_env : 32)) {
         const int pp = mfpp_env ? (mfpp_env == 1 ? 1 : 2) : (D <= 64 ? 1 : 2);
         const int P = (256 / D) * pp;
         dim3 g(gdm_cdiv(n, P), B);
