@@ -79,6 +79,85 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float p
     return r;
 }
 
+// K == 1 with TWO queries per lane and the distance arithmetic on the packed fp32 ALU (v_pk_add_f32 / v_pk_mul_f32: two IEEE fp32
+// operations per instruction, each component rounded exactly like the scalar form; -ffp-contract=off keeps mul and add apart): one LDS
+// read and 8 packed + 4 scalar vector instructions per TWO pairs instead of 10 per pair.  Same scan order per query (support points
+// t, t + T, ... of each tile, strict '<'), same merge: results identical to knn_kernel<1>.
+typedef __attribute__((ext_vector_type(2))) float knn_f32x2;
+
+__global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab)
+{
+    __shared__ float4 tile[KNN_TILE];
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
+    const KnnJobDev& job = tab.jobs[j];
+    const int local = bid - job.block_begin;
+    const int b = local / job.blocks_per_b;
+    const int qb = local - b * job.blocks_per_b;
+    const int logT = job.logT;
+    const int T = 1 << logT;
+    const int S = job.S, Q = job.Q;
+    const int tid = threadIdx.x;
+    const int t = tid & (T - 1);
+    const int qpb = KNN_BLOCK >> logT;                         // queries per block and slot
+    const int q0 = qb * (2 * qpb) + (tid >> logT), q1 = q0 + qpb;
+    const bool valid0 = q0 < Q, valid1 = q1 < Q;
+    const int qc0 = valid0 ? q0 : Q - 1, qc1 = valid1 ? q1 : Q - 1;
+    const float* sup = job.support + (long long)b * job.support_bstride;
+    const float* qr0 = job.query + (long long)b * job.query_bstride + (long long)qc0 * 3;
+    const float* qr1 = job.query + (long long)b * job.query_bstride + (long long)qc1 * 3;
+    const knn_f32x2 qx = {qr0[0], qr1[0]}, qy = {qr0[1], qr1[1]}, qz = {qr0[2], qr1[2]};
+    float d0 = INFINITY, d1 = INFINITY;
+    int i0 = IDX_EMPTY, i1 = IDX_EMPTY;
+    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
+        __syncthreads();
+        const int npt = min(KNN_TILE, S - tile0);
+        for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
+            float4 v;
+            if (p < npt) {
+                const float* s3 = sup + (long long)(tile0 + p) * 3;
+                v = make_float4(s3[0], s3[1], s3[2], 0.f);
+            } else {
+                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            }
+            tile[p] = v;
+        }
+        __syncthreads();
+        const int steps = (npt + T - 1) >> logT;
+#pragma unroll 4
+        for (int s = 0; s < steps; ++s) {
+            const int p = (s << logT) + t;
+            const float4 v = tile[p];
+            const knn_f32x2 ex = qx - knn_f32x2{v.x, v.x}, ey = qy - knn_f32x2{v.y, v.y}, ez = qz - knn_f32x2{v.z, v.z};
+            knn_f32x2 r = ex * ex;
+            r = r + ey * ey;
+            r = r + ez * ez;
+            const int pi = tile0 + p;
+            const bool c0 = r.x < d0, c1 = r.y < d1;              // strict: an equal distance has a larger index
+            d0 = c0 ? r.x : d0; i0 = c0 ? pi : i0;
+            d1 = c1 ? r.y : d1; i1 = c1 ? pi : i1;
+        }
+    }
+    // merge the T partial results of each query: lexicographic (d, idx) arg-min
+    for (int m = 1; m < T; m <<= 1) {
+        const float od0 = __shfl_xor(d0, m, 64), od1 = __shfl_xor(d1, m, 64);
+        const int oi0 = __shfl_xor(i0, m, 64), oi1 = __shfl_xor(i1, m, 64);
+        if (od0 < d0 || (od0 == d0 && oi0 < i0)) { d0 = od0; i0 = oi0; }
+        if (od1 < d1 || (od1 == d1 && oi1 < i1)) { d1 = od1; i1 = oi1; }
+    }
+    if (t == 0) {
+        if (valid0) {
+            job.idx[(long long)b * Q + q0] = i0 == IDX_EMPTY ? 0 : i0;
+            if (job.d2) job.d2[(long long)b * Q + q0] = isinf(d0) ? 3.402823466e+38f : d0;
+        }
+        if (valid1) {
+            job.idx[(long long)b * Q + q1] = i1 == IDX_EMPTY ? 0 : i1;
+            if (job.d2) job.d2[(long long)b * Q + q1] = isinf(d1) ? 3.402823466e+38f : d1;
+        }
+    }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const KnnTable tab)
 {
@@ -688,6 +767,13 @@ void fill_job(KnnJobDev& d, const gdm_knn_job& j)
 // K == 1 jobs: per-lane best + shuffle merge
 int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
 {
+    // two queries per lane on the packed fp32 ALU (GDM_KNN1_PAIR=0: one query per lane, for A/B)
+    static int pair_env = -1;
+    if (pair_env < 0) {
+        const char* e = getenv("GDM_KNN1_PAIR");
+        pair_env = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool pair = pair_env != 0;
     KnnTable tab;
     tab.njobs = 0;
     tab.B = B;
@@ -697,11 +783,15 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
         KnnJobDev& d = tab.jobs[tab.njobs++];
         fill_job(d, jobs[i]);
         d.logT = pick_logT(d.S);
-        d.blocks_per_b = gdm_cdiv(d.Q, KNN_BLOCK >> d.logT);
+        d.blocks_per_b = gdm_cdiv(d.Q, (pair ? 2 : 1) * (KNN_BLOCK >> d.logT));
         d.block_begin = nblocks;
         nblocks += d.blocks_per_b * B;
     }
     if (tab.njobs == 0) return 0;
+    if (pair) {
+        hipLaunchKernelGGL(knn1_pair_kernel, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+        return gdm_launch_status("knn1_pair_kernel");
+    }
     hipLaunchKernelGGL(knn_kernel<1>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
     return gdm_launch_status("knn_kernel<1>");
 }
