@@ -202,3 +202,21 @@ def test_objects_across_gpus_shards_are_disjoint_and_cover_every_object():
             assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
     a = train_lm.build_parser().parse_args(["--objects-across-gpus"])
     assert a.objects_across_gpus
+
+
+def test_training_gemm_host_rules():
+    """Host-side choices of the training GEMMs (no GPU): the K split of the pixel-contraction weight gradient divides the chunk count,
+    keeps >= 4 chunks per part and about one round of workgroups; the one-pass small-channel form and the MFMA GEMM are never chosen
+    for CPU tensors (the product path has no CPU fallback: those calls go to torch.bmm inside autograd only on the GPU)."""
+    import torch
+    from geometric_aware_dense_matching_amd import ops, settings
+    for nchunk, tiles in ((48, 72), (8, 72), (768, 4), (5, 1), (1, 1), (192, 36)):
+        parts = ops._wgrad_parts(nchunk, tiles)
+        assert parts >= 1 and nchunk % parts == 0
+        assert parts == 1 or (nchunk // parts >= 4 and parts * tiles <= 320)
+    x, go = torch.zeros(2, 32, 4096), torch.zeros(2, 32, 4096)
+    assert not ops.wgrad_direct_supported(x, go) and not ops.wgrad_direct_supported(x, go, bias=True)
+    assert not ops.gemm_wgrad_supported(torch.zeros(2, 256, 4096), torch.zeros(2, 256, 4096))
+    # every training-side switch of this round is registered (the all-switches-off parity test iterates this list)
+    for name in ("USE_MFMA_GEMM_TRAIN", "USE_DIRECT_WGRAD", "USE_GATHERED_FINAL", "USE_MFMA_WGRAD", "USE_GEMM_CONV1X1_TRAIN"):
+        assert isinstance(getattr(settings, name), bool)
