@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time the eager step loop only (no hipGraph capture)")
     ap.add_argument("--graph-only", action="store_true", help="headline = the hipGraph replays even where the eager loop is faster")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-32 / mesh-cached / per-kernel roofline legs (and the heavy ones)")
+    ap.add_argument("--no-forked", action="store_true", help="do not offer the side-stream (forked) hipGraph form to the timing")
     ap.add_argument("--no-heavy-extras", action="store_true", help="skip the legs that run after the JSON line (exact-f32, DGCNN, training step)")
     return ap.parse_args()
 
@@ -489,8 +490,8 @@ def main():
     stage_ev = []
     step_pool = ops.BufferPool()               # the step's scratch buffers: owned here, shared by the eager and the captured form
 
-    def step(record=False):
-        with ops.buffer_pool(step_pool):
+    def step(record=False, pool=None):
+        with ops.buffer_pool(pool if pool is not None else step_pool):
             if record:
                 e = [ev() for _ in range(5)]
                 e[0].record()
@@ -523,6 +524,8 @@ def main():
 
     graph = None
     check = None
+    graph_forked = None
+    check_forked = None
     launch = "eager (one host call per kernel)"
     with torch.no_grad():
         # warm-up fills the per-module caches (folded BatchNorms, packed weights) and brings the allocator to its steady state.  With
@@ -559,37 +562,79 @@ def main():
             else:
                 graph = None
                 launch = "eager (the hipGraph replay failed its check: see graph_check)"
+            # A THIRD form, offered to the timing only if it passes the same check on this box: the same step captured with the
+            # mesh branch, the pyramid and the point branch forked onto side streams (settings.USE_SIDE_STREAMS; in a graph the forks are
+            # parallel branches, so small point-branch kernels fill the CUs the convolution launches leave idle).  It is compared with
+            # the SINGLE-STREAM eager steps above; a failed check or capture only drops this candidate.
+            if graph is not None and not settings.USE_SIDE_STREAMS and not args.no_forked:
+                try:
+                    settings.USE_SIDE_STREAMS = True
+                    forked_pool = ops.BufferPool()
+                    for _ in range(2):
+                        step(pool=forked_pool)
+                    torch.cuda.synchronize()
+                    graph_forked = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_forked):
+                        forked_out = step(pool=forked_pool)
+                    graph_forked.replay()
+                    graph_forked.replay()
+                    torch.cuda.synchronize()
+                    check_forked = graph_check(torch, ref, forked_out, ref2)
+                except Exception as e:                         # noqa: BLE001
+                    check_forked = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+                    torch.cuda.synchronize()
+                finally:
+                    settings.USE_SIDE_STREAMS = False
+                if not check_forked.get("ok"):
+                    graph_forked = None
             del ref, ref2
         sync_all()
         # K steps of each launch form, each bracketed as the contract asks; the headline is the faster one (both are the same kernels
         # on the same inputs: the check above is what makes them interchangeable) and the line says which it was
-        dt_graph = None
+        dt_graph = dt_forked = None
+        # (every rank passes every barrier, whether or not it has the form to time: a rank whose capture failed must not hang the others)
+        t0 = time.perf_counter()
         if graph is not None:
-            t0 = time.perf_counter()
             for _ in range(args.steps):
                 graph.replay()
-            sync_all()
+        sync_all()
+        if graph is not None:
             dt_graph = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if graph_forked is not None:
+            for _ in range(args.steps):
+                graph_forked.replay()
+        sync_all()
+        if graph_forked is not None:
+            dt_forked = time.perf_counter() - t0
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
         dt_enqueue = time.perf_counter() - t1                      # host time to issue the eager steps (no wait for the GPU)
         sync_all()
         dt_eager = time.perf_counter() - t1
-        if dt_graph is not None and (args.graph_only or dt_graph <= dt_eager):
-            dt = dt_graph
-        else:
-            dt = dt_eager
-            if graph is not None:
-                launch = "eager (one host call per kernel; the hipGraph replay of the same step was slower on this box: see launch_forms)"
         # stage breakdown from a few more, instrumented, eager steps OUTSIDE the timed region
         for _ in range(min(args.steps, 5)):
             step(record=True)
         sync_all()
+    # the forms are compared on their MAX over ranks (each form was timed by all ranks at once); a form some rank could not offer is out
+    INF = float("inf")
+    forms = [dt_forked if dt_forked is not None else INF, dt_graph if dt_graph is not None else INF, INF if args.graph_only and dt_graph is not None else dt_eager]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor(forms, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        forms = [float(v) for v in t.tolist()]
+    which = min(range(3), key=lambda i: forms[i])
+    dt = forms[which]
+    side_streams_used = bool(settings.USE_SIDE_STREAMS)
+    if which == 0:
+        launch = "hipGraph replay of the whole step with the mesh branch, the pyramid and the point branch forked onto side streams (checked against the single-stream eager step: graph_check_forked)"
+        side_streams_used = True
+    elif which == 1:
+        launch = "hipGraph replay of the whole step (one host call per step)"
+    elif graph is not None:
+        launch = "eager (one host call per kernel; the hipGraph replays of the same step were slower on this box: see launch_forms)"
+    if world > 1:
         # every rank's check rides along: one rank outside tolerance is reported, it does not stop the others
         flag = torch.tensor([0.0 if (check is None or check.get("ok")) else 1.0], dtype=torch.float64,
                             device=dev if args.backend == "nccl" else "cpu")
@@ -613,14 +658,15 @@ def main():
                    "match_precision": args.precision,
                    "product_arithmetic": "exact f32" if args.exact_f32 else
                    "split-bf16 MFMA x3 (fp32 accumulate) for matching, trunk convolutions and 1x1 mixes; f32 elsewhere",
-                   "launch": launch, "side_streams": bool(settings.USE_SIDE_STREAMS),
+                   "launch": launch, "side_streams": side_streams_used,
                    "mesh_cached": bool(args.cache_mesh), "parallelism": "dp%d" % world},
         "stage_ms": {"knn_pyramid": round(pyr_ms, 3), "geomatch_forward": round(fwd_ms, 3),
                      "match_pack": round(pack_ms, 3), "match_kernel": round(match_ms, 3)},
-        "graph_check": check,
+        "graph_check": check, "graph_check_forked": check_forked,
         "launch_forms": {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3),
                          "eager_host_enqueue_ms_per_step": round(dt_enqueue / args.steps * 1e3, 3),
-                         "graph_ms_per_step": round(dt_graph / args.steps * 1e3, 3) if dt_graph is not None else None},
+                         "graph_ms_per_step": round(dt_graph / args.steps * 1e3, 3) if dt_graph is not None else None,
+                         "graph_forked_ms_per_step": round(dt_forked / args.steps * 1e3, 3) if dt_forked is not None else None},
         "roofline": None, "roofline_fused": None, "rooflines": None, "cpu_baseline": None, "extras": None,
         "build": _lib.build_record(),
     }

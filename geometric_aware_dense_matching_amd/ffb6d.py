@@ -209,6 +209,8 @@ class FFB6DEmb(nn.Module):
         # build (pyramid.build_pyramid(..., overlap=True)) is waited for by EACH consuming stream before its first index use.
         from . import pyramid as _pyr
         overlap = settings.USE_SIDE_STREAMS and "point" in settings.SIDE_PARTS and fused_eval(inputs["rgb"], self)
+        if overlap and settings.USE_TWO_STREAM_PIPELINE:
+            return self._forward_two_streams(inputs, rgb_emb, parts)
         if not overlap:
             _pyr.wait_ready(inputs)
         p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
@@ -277,6 +279,89 @@ class FFB6DEmb(nn.Module):
             rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
             bs, di, _, _ = rgb_emb.size()
             rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+        if parts:
+            return rgb_emb_c, p_emb
+        return torch.cat([rgb_emb_c, p_emb], dim=1)
+
+    def _forward_two_streams(self, inputs, rgb_emb, parts):
+        """The inference forward as a two-stream pipeline (settings.USE_SIDE_STREAMS): the IMAGE stream (the current one) runs the
+        trunk / up stages and the point-to-pixel fusions, the POINT stream (side stream 0) the RandLA blocks, the decoder layers and the
+        pixel-to-point fusions.  Per stage each stream waits ONCE for the other's product (an event): the point stream for the image
+        stage's map (`rgb_emb0`, read by the r2p gather), the image stream for the pooled / decoded point features (`p_emb0`, read by
+        the p2r fusion); otherwise they run ahead independently -- the r2p chain of stage i and the RandLA block of stage i + 1 sit in
+        the shadow of the convolutions of stage i + 1.  Same kernels on the same operands as the single-stream order: bit-identical
+        (tests/test_gpu_headline.py::test_timed_configuration_bit_exact_across_launch_forms).  Every tensor that crosses is recorded
+        on the stream that did not allocate it."""
+        from . import pyramid as _pyr
+        dev = inputs["rgb"].device
+        M = torch.cuda.current_stream(dev)
+        S = ops.side_stream(dev, 0)
+
+        def to(stream, *ts):
+            for t in ts:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(stream)
+
+        def event(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        S.wait_stream(M)
+        _pyr.wait_ready(inputs)                                               # the image stream's own wait
+        to(S, inputs["cld_rgb_nrm"])
+        with torch.cuda.stream(S):
+            _pyr.wait_ready(inputs)                                           # the point stream's own wait
+            p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)  # [B,8,N,1]
+        ds_emb = []
+        for i_ds in range(4):
+            rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
+            ev_rgb0 = event(M)
+            bs, c, hr, wr = rgb_emb0.size()
+            with torch.cuda.stream(S):
+                f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
+                p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
+                ev_p0 = event(S)
+                S.wait_event(ev_rgb0)
+                to(S, rgb_emb0)
+                r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
+                r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
+                p_emb = self.ds_fuse_r2p_fuse_layers[i_ds].forward_segs([p_emb0, r2p_emb])
+            if i_ds == 0:
+                ds_emb.append(f_encoder_i)
+            ds_emb.append(p_emb)
+            M.wait_event(ev_p0)
+            to(M, p_emb0)
+            rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,
+                                     inputs["p2r_ds_nei_idx%d" % i_ds])
+        n_up = len(self.rndla_up_stages)
+        sparse_final = self._sparse_final_ok(inputs["rgb"])
+        for i_up in range(n_up - 1):
+            rgb_emb0 = self.cnn_up_stages[i_up](rgb_emb)
+            ev_rgb0 = event(M)
+            bs, c, hr, wr = rgb_emb0.size()
+            with torch.cuda.stream(S):
+                p_emb0 = self.rndla_up_stages[i_up].forward_segs([ds_emb[-i_up - 2], (p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])])
+                ev_p0 = event(S)
+                S.wait_event(ev_rgb0)
+                to(S, rgb_emb0)
+                r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_up_nei_idx%d" % i_up])
+                r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)
+                p_emb = self.up_fuse_r2p_fuse_layers[i_up].forward_segs([p_emb0, r2p_emb])
+            M.wait_event(ev_p0)
+            to(M, p_emb0)
+            rgb_emb = self._p2r_fuse(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], rgb_emb0, p_emb0,
+                                     inputs["p2r_up_nei_idx%d" % i_up], pixel_major=sparse_final and i_up == n_up - 2)
+        with torch.cuda.stream(S):
+            p_emb = self.rndla_up_stages[n_up - 1].forward_segs([ds_emb[0], (p_emb, inputs["cld_interp_idx0"])]).squeeze(-1)
+        if sparse_final:
+            rgb_emb_c = self._final_at_choose(rgb_emb, (hr, wr), inputs["choose"])
+        else:
+            rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
+            bs, di, _, _ = rgb_emb.size()
+            rgb_emb_c = ops.gather_nn(rgb_emb.view(bs, di, -1), inputs["choose"].reshape(bs, -1, 1))
+        M.wait_stream(S)
+        to(M, p_emb)
         if parts:
             return rgb_emb_c, p_emb
         return torch.cat([rgb_emb_c, p_emb], dim=1)
