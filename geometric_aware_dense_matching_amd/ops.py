@@ -45,6 +45,19 @@ def side_stream(device, which=0):
     return st
 
 
+def _stream_lane(device):
+    """Which ROLE the current stream plays for the scratch-buffer pools: ("side", k) for side stream k of the device, "main" for any
+    other stream.  The pools are keyed by role, not by stream handle: a hipGraph capture runs on a stream of its own (torch's capture
+    stream), and a pool keyed by handle missed every buffer the eager warm-up had made -- the capture then allocated and ZERO-FILLED
+    them again inside the graph (12 fill kernels, 0.13-0.15 ms of every replay).  A BufferPool serves ONE step at a time."""
+    h = torch.cuda.current_stream(device).cuda_stream
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    for (d, which), st in _side_streams.items():
+        if d == idx and st.cuda_stream == h:
+            return ("side", which)
+    return "main"
+
+
 class fork:
     """with ops.fork(device, which) as f: ...   -- the body is enqueued on side stream `which`, which first waits for everything
     already on the current stream (and for the `after` events, if given); `f.join(*tensors)` afterwards makes the current stream
@@ -1417,7 +1430,7 @@ def _packed_buffer(B, C, H, W, device, avoid=None):
     nbytes = _lib.lib().gdm_conv3x3_act_bytes(B, C, H, W)
     if _capturing_unscoped():
         return torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    key = (B, C, H, W, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (B, C, H, W, device.index, _stream_lane(device))
     pool = _pool.packed.setdefault(key, [])
     for buf in pool:
         if avoid is None or buf.data_ptr() != avoid.data_ptr():
@@ -1622,7 +1635,7 @@ def upsample_bilinear(x, size):
 def _workspace(nbytes, device):
     if _capturing_unscoped():
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream_lane(device))
     ws = _pool.workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -1,11 +1,13 @@
 """Ordered kernel list of ONE step from a rocprofv3 kernel trace: start offset, duration, idle gap before it.  Development aid.
-usage: step_sequence.py <kernel_trace.csv> [marker substring, default knn_grid_ranges]"""
+usage: step_sequence.py <kernel_trace.csv> [marker substring, default knn_grid_ranges] [steps back from the last one, default 0]
+(bench.py --steps K: the K forked replays are steps K+5 .. 2K+4 back from the end, the K single-stream replays 2K+5 .. 3K+4 back)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "knn_grid_ranges"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+a, b = idx[-2 - back], idx[-1 - back]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None
 tot = gap_tot = 0
