@@ -770,11 +770,15 @@ void fill_job(KnnJobDev& d, const gdm_knn_job& j)
 // K == 1 jobs: per-lane best + shuffle merge
 int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
 {
-    // two queries per lane on the packed fp32 ALU (GDM_KNN1_PAIR=0: one query per lane, for A/B)
+    // GDM_KNN1_PAIR=1: two queries per lane on the packed fp32 ALU (knn1_pair_kernel; 47.8 -> 39.4 us for 512 x 16384).  NOT the
+    // default: correct in every ordered run (all parity tests), but in forked hipGraph replays launched back to back -- the pyramid on
+    // its side stream beside the previous replay's model kernels -- a few K = 1 results per ~10 replays came out as if single support
+    // points had been missing from the LDS tile (tools/diag_fork_race.py: 20-90 differing arrays in 40 rounds of 5 replays; 0 with
+    // knn_kernel<1>, 0 with a synchronize between replays).  The cause was not found in the round; the kernel stays for A/B.
     static int pair_env = -1;
     if (pair_env < 0) {
         const char* e = getenv("GDM_KNN1_PAIR");
-        pair_env = (e && e[0] == '0') ? 0 : 1;
+        pair_env = (e && e[0] == '1') ? 1 : 0;
     }
     const bool pair = pair_env != 0;
     KnnTable tab;

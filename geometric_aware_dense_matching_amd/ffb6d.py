@@ -120,7 +120,20 @@ class FFB6DEmb(nn.Module):
             layer.__dict__[slot] = cache
         return cache[1]
 
-    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False):
+    def _p2r_point_term(self, pre_layer, fuse_layer, c, p_emb0):
+        """The point half of the p2r fusion, W_b . pre(p_emb0), at the points -- exactly what _p2r_fuse computes first (same branch
+        conditions); the two-stream pipeline forms it on the POINT stream so that the image stream only waits for the finished term.
+        None when _p2r_fuse would not take a path with a separate point term."""
+        if not fused_eval(p_emb0, self) or act_code(getattr(fuse_layer, "activation", None)) is None or not settings.USE_POINTWISE:
+            return None
+        bs = p_emb0.shape[0]
+        wa, wb = self._split_fuse_weight(fuse_layer, c)
+        pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
+        if c == 64 and wa.shape[0] == 64 and settings.USE_MFMA_GEMM:
+            return ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"), point_major=True)       # [B, n', 64]
+        return ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"))                             # [B, Cout, n']
+
+    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False, point_term=None):
         """fuse(cat(rgb_emb0, nearest_interp(pre(p_emb0)))) (ffb6d.py:216-222,252-258).  Eval: the point half of the
         1x1 fuse convolution runs at the points (a 1x1 conv commutes with the gather), the pixel half is a GEMM with half
         the K, and gather + add + BN + ReLU is one HIP launch; no concat, no full-resolution point features."""
@@ -134,11 +147,14 @@ class FFB6DEmb(nn.Module):
                     # bound by the map's read + write; the point term is formed point-major ([B, n', 64]: one contiguous row per
                     # gathered point) by the same library GEMM with its operands swapped
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
-                    pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
-                    if settings.USE_POINTWISE:
-                        t_pm = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"), point_major=True)   # [B, n', 64]
+                    if point_term is not None:
+                        t_pm = point_term
                     else:
-                        t_pm = torch.matmul(pp.transpose(1, 2), wb.t())
+                        pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
+                        if settings.USE_POINTWISE:
+                            t_pm = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"), point_major=True)   # [B, n', 64]
+                        else:
+                            t_pm = torch.matmul(pp.transpose(1, 2), wb.t())
                     cache = fuse_layer.__dict__.get("_gdm_wa_pk")
                     if cache is None or cache[0] is not wa:
                         cache = (wa, ops.pack_rows64(wa))
@@ -146,11 +162,14 @@ class FFB6DEmb(nn.Module):
                     y = ops.conv64_gather_add_act_mfma(rgb_emb0.reshape(bs, c, hr * wr), cache[1], t_pm, idx.reshape(bs, -1), scale, shift,
                                                        code[0], code[1], pixel_major=pixel_major, t_point_major=True)
                     return y if pixel_major else y.view(bs, -1, hr, wr)
-                pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
-                if settings.USE_POINTWISE:
-                    t = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"))   # [B,Cout,n'] at the points
+                if point_term is not None:
+                    t = point_term
                 else:
-                    t = ops.wx(wb, pp)
+                    pp = pre_layer(p_emb0).reshape(bs, wb.shape[1], -1)
+                    if settings.USE_POINTWISE:
+                        t = ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"))   # [B,Cout,n'] at the points
+                    else:
+                        t = ops.wx(wb, pp)
                 if c == 64 and wa.shape[0] == 64:
                     # K = 64: GEMM + gather + add + BN + ReLU in ONE pass over the pixels (exact fp32 FMAs)
                     scale, shift = folded_bn(fuse_layer.normlayer.bn)
@@ -321,6 +340,7 @@ class FFB6DEmb(nn.Module):
             with torch.cuda.stream(S):
                 f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
                 p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
+                pt = self._p2r_point_term(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], c, p_emb0)
                 ev_p0 = event(S)
                 S.wait_event(ev_rgb0)
                 to(S, rgb_emb0)
@@ -331,9 +351,9 @@ class FFB6DEmb(nn.Module):
                 ds_emb.append(f_encoder_i)
             ds_emb.append(p_emb)
             M.wait_event(ev_p0)
-            to(M, p_emb0)
+            to(M, p_emb0, pt)
             rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,
-                                     inputs["p2r_ds_nei_idx%d" % i_ds])
+                                     inputs["p2r_ds_nei_idx%d" % i_ds], point_term=pt)
         n_up = len(self.rndla_up_stages)
         sparse_final = self._sparse_final_ok(inputs["rgb"])
         for i_up in range(n_up - 1):
@@ -342,6 +362,7 @@ class FFB6DEmb(nn.Module):
             bs, c, hr, wr = rgb_emb0.size()
             with torch.cuda.stream(S):
                 p_emb0 = self.rndla_up_stages[i_up].forward_segs([ds_emb[-i_up - 2], (p_emb, inputs["cld_interp_idx%d" % (n_up - i_up - 1)])])
+                pt = self._p2r_point_term(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], c, p_emb0)
                 ev_p0 = event(S)
                 S.wait_event(ev_rgb0)
                 to(S, rgb_emb0)
@@ -349,9 +370,9 @@ class FFB6DEmb(nn.Module):
                 r2p_emb = self.up_fuse_r2p_pre_layers[i_up](r2p_emb)
                 p_emb = self.up_fuse_r2p_fuse_layers[i_up].forward_segs([p_emb0, r2p_emb])
             M.wait_event(ev_p0)
-            to(M, p_emb0)
+            to(M, p_emb0, pt)
             rgb_emb = self._p2r_fuse(self.up_fuse_p2r_pre_layers[i_up], self.up_fuse_p2r_fuse_layers[i_up], rgb_emb0, p_emb0,
-                                     inputs["p2r_up_nei_idx%d" % i_up], pixel_major=sparse_final and i_up == n_up - 2)
+                                     inputs["p2r_up_nei_idx%d" % i_up], pixel_major=sparse_final and i_up == n_up - 2, point_term=pt)
         with torch.cuda.stream(S):
             p_emb = self.rndla_up_stages[n_up - 1].forward_segs([ds_emb[0], (p_emb, inputs["cld_interp_idx0"])]).squeeze(-1)
         if sparse_final:

@@ -364,8 +364,13 @@ def test_timed_configuration_bit_exact_across_launch_forms(headline_model):
         return {k: v.clone() for k, v in o.items()}
 
     def same(a, b, what):
+        bad = []
         for k in a:
-            assert torch.equal(a[k], b[k]), "%s: %s differs (%d entries)" % (what, k, int((a[k] != b[k]).sum()))
+            if not torch.equal(a[k], b[k]):
+                pos = (a[k] != b[k]).nonzero()[:4].tolist()
+                bad.append("%s differs in %d entries, first at %s: want %s got %s" % (
+                    k, int((a[k] != b[k]).sum()), pos, [a[k][tuple(p)].item() for p in pos], [b[k][tuple(p)].item() for p in pos]))
+        assert not bad, "%s: %s" % (what, "; ".join(bad))
 
     def graphed(tag):
         pool = ops.BufferPool()
