@@ -587,7 +587,6 @@ def main():
                     settings.USE_SIDE_STREAMS = False
                 if not check_forked.get("ok"):
                     graph_forked = None
-            del ref, ref2
         sync_all()
         # K steps of each launch form, each bracketed as the contract asks; the headline is the faster one (both are the same kernels
         # on the same inputs: the check above is what makes them interchangeable) and the line says which it was
@@ -600,6 +599,12 @@ def main():
         sync_all()
         if graph is not None:
             dt_graph = time.perf_counter() - t0
+            # the TIMED replays themselves (back to back, unlike the two of the first check) are compared with the eager step again
+            after = graph_check(torch, ref, graph_out, ref2)
+            check["after_timed_replays_ok"] = bool(after.get("ok"))
+            check["after_timed_replays_bit_identical"] = bool(after.get("bit_identical"))
+            if not after.get("ok"):
+                dt_graph = None
         t0 = time.perf_counter()
         if graph_forked is not None:
             for _ in range(args.steps):
@@ -607,6 +612,13 @@ def main():
         sync_all()
         if graph_forked is not None:
             dt_forked = time.perf_counter() - t0
+            after = graph_check(torch, ref, forked_out, ref2)
+            check_forked["after_timed_replays_ok"] = bool(after.get("ok"))
+            check_forked["after_timed_replays_bit_identical"] = bool(after.get("bit_identical"))
+            if not after.get("ok"):
+                dt_forked = None                                   # a form whose timed replays drifted is not the headline
+        if not args.eager:
+            del ref, ref2
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
