@@ -185,10 +185,21 @@ class GeoMatch(nn.Module):
         emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
         if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
             # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
-            with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
-                mesh_features = self.mesh_features()
-            rgbd_emb = emb(inputs)
-            f.join(mesh_features)
+            if settings.MESH_FORK_LATE:
+                # enqueued BEHIND the embedding (it only waits for an event recorded before it): in a hipGraph the branch is still a
+                # root, but the executor -- which spreads a graph over very few hardware queues, in node order -- then keeps the image
+                # branch on a queue of its own instead of queueing layer1 behind the mesh kernels (tools/step_sequence.py, Queue_Id)
+                ev0 = torch.cuda.Event()
+                ev0.record(torch.cuda.current_stream(rgb.device))
+                rgbd_emb = emb(inputs)
+                with ops.fork(rgb.device, 1, start=ev0) as f:
+                    mesh_features = self.mesh_features()
+                f.join(mesh_features)
+            else:
+                with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
+                    mesh_features = self.mesh_features()
+                rgbd_emb = emb(inputs)
+                f.join(mesh_features)
         else:
             rgbd_emb = emb(inputs)
             mesh_features = self.mesh_features()

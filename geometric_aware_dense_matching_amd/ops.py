@@ -67,14 +67,18 @@ class fork:
     stream that did not allocate it -- `f.use(t)` for a tensor of the current stream that the body reads, `f.join(t, ...)` for
     the tensors the body made -- so the caching allocator never hands its block out again before both streams are done with it."""
 
-    def __init__(self, device, which=0, after=()):
+    def __init__(self, device, which=0, after=(), start=None):
         self.side = side_stream(device, which)
         self.cur = torch.cuda.current_stream(device)
         self.after = tuple(after) if isinstance(after, (tuple, list)) else (after,)
+        self.start = start          # an event of the current stream: the body waits for IT instead of for everything enqueued so far
         self._ctx = None
 
     def __enter__(self):
-        self.side.wait_stream(self.cur)
+        if self.start is not None:
+            self.side.wait_event(self.start)
+        else:
+            self.side.wait_stream(self.cur)
         for ev in self.after:
             if ev is not None:
                 self.side.wait_event(ev)           # waiting for an event of the same stream is free
