@@ -327,10 +327,9 @@ class FFB6DEmb(nn.Module):
             return e
 
         S.wait_stream(M)
-        _pyr.wait_ready(inputs)                                               # the image stream's own wait
         to(S, inputs["cld_rgb_nrm"])
         with torch.cuda.stream(S):
-            _pyr.wait_ready(inputs)                                           # the point stream's own wait
+            _pyr.wait_ready(inputs, cloud_only=True)                          # the point stream's own wait: the cloud's searches only
             p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)  # [B,8,N,1]
         ds_emb = []
         for i_ds in range(4):
@@ -344,12 +343,16 @@ class FFB6DEmb(nn.Module):
                 ev_p0 = event(S)
                 S.wait_event(ev_rgb0)
                 to(S, rgb_emb0)
+                if i_ds == 0:
+                    _pyr.wait_ready(inputs)                                   # the rest of the pyramid: the r2p / interpolation indices
                 r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
                 r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
                 p_emb = self.ds_fuse_r2p_fuse_layers[i_ds].forward_segs([p_emb0, r2p_emb])
             if i_ds == 0:
                 ds_emb.append(f_encoder_i)
             ds_emb.append(p_emb)
+            if i_ds == 0:
+                _pyr.wait_ready(inputs)                                       # the image stream's own wait: its first index use is this fusion
             M.wait_event(ev_p0)
             to(M, p_emb0, pt)
             rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,

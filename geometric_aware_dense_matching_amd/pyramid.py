@@ -27,6 +27,7 @@ def cloud_from_inputs(cld_rgb_nrm):
 
 
 READY = "_pyramid_ready"          # key of the event recorded behind an overlapped pyramid build
+READY_CLOUD = "_pyramid_ready_cloud"   # ... and of the one behind its first part: the cloud's own K = 16 searches and pooling indices
 KEEP = "_pyramid_keep"            # key of the buffers the build keeps alive with its results (kNN workspace, strided grids)
 PYR_STREAM = 2                    # side-stream number of an overlapped build (its own: the point branch forks onto 0, the mesh branch onto 1)
 
@@ -47,7 +48,7 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
             pyr = build_pyramid(cld, dpt_xyz, _keep=keep)
             ev = torch.cuda.Event()
             ev.record(f.side)
-        pyr[READY] = ev                 # the only two non-tensor entries, and only of an overlapped build
+        pyr[READY] = ev                 # the non-tensor entries, and only of an overlapped build
         pyr[KEEP] = keep
         return pyr
     B, N, _ = cld.shape
@@ -79,20 +80,39 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
         names += ["r2p_up_nei_idx%d" % i, "p2r_up_nei_idx%d" % i]
     if _keep is not None:
         _keep += dense
-    outs = ops.knn_jobs(jobs, B, keep_workspace=_keep)
-
-    pyr = dict(zip(names, outs))
+    # Two launches of the job table: first what the point branch's first RandLA block needs -- the cloud's own K = 16 searches (one
+    # knn_wave launch) and the pooling indices cut from them -- then the searches against and from the pixel grids and the
+    # nearest-interpolation ones.  An overlapped build records an event behind the first part (READY_CLOUD): the point stream starts
+    # ~170 us earlier than behind the whole pyramid, which is what the image stream waits for at the first fusion.
+    first = [i for i, nm in enumerate(names) if nm.startswith("cld_nei_idx")]
+    rest = [i for i in range(len(jobs)) if i not in first]
+    outs = [None] * len(jobs)
+    for i, o in zip(first, ops.knn_jobs([jobs[i] for i in first], B, keep_workspace=_keep)):
+        outs[i] = o
+    pyr = dict((names[i], outs[i]) for i in first)
     subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])     # pooling indices: prefix rows, dense
+    if _keep is not None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(cld.device))
+        pyr[READY_CLOUD] = ev
+    for i, o in zip(rest, ops.knn_jobs([jobs[i] for i in rest], B, keep_workspace=_keep)):
+        outs[i] = o
+    pyr.update((names[i], outs[i]) for i in rest)
+    pyr = dict([(nm, pyr[nm]) for nm in names] + [(k, v) for k, v in pyr.items() if k not in names])     # the reference's key order first
     for i in range(4):
         pyr["cld_xyz%d" % i] = levels[i]
         pyr["cld_sub_idx%d" % i] = subs[i]
     return pyr
 
 
-def wait_ready(inputs, stream=None):
+def wait_ready(inputs, stream=None, cloud_only=False):
     """Make `stream` (default: the current one) wait for an overlapped pyramid build, if the inputs carry one, and record the
-    pyramid's tensors on it.  Idempotent and cheap: every consuming stream calls it before its first index use."""
-    ev = inputs.get(READY)
+    pyramid's tensors on it.  Idempotent and cheap: every consuming stream calls it before its first index use.  cloud_only: wait
+    only for the first part of the build (cld_nei_idx*, cld_sub_idx*, cld_xyz*: what a RandLA block reads); a later full wait is
+    still needed before any other index is used."""
+    ev = inputs.get(READY_CLOUD) if cloud_only else None
+    if ev is None:
+        ev = inputs.get(READY)
     if ev is None:
         return
     st = stream or torch.cuda.current_stream()
