@@ -180,6 +180,7 @@ class GeoMatch(nn.Module):
         if not end_points:
             end_points = {}
         rgb = inputs["rgb"]
+        late_join = None
         heads = self._fused_heads(rgb)
         # the fused heads read the two halves of the embedding in place: no concat launch
         emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
@@ -194,7 +195,9 @@ class GeoMatch(nn.Module):
                 rgbd_emb = emb(inputs)
                 with ops.fork(rgb.device, 1, start=ev0) as f:
                     mesh_features = self.mesh_features()
-                f.join(mesh_features)
+                late_join = f if heads is not None else None      # the fused heads do not read the mesh: join behind them
+                if late_join is None:
+                    f.join(mesh_features)
             else:
                 with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
                     mesh_features = self.mesh_features()
@@ -207,6 +210,8 @@ class GeoMatch(nn.Module):
             # feature_encoding_layer, normalize_feature_layer, the residual add and seg_layer: nine per-point 1x1 convolutions, one launch
             a, b = rgbd_emb if isinstance(rgbd_emb, tuple) else (rgbd_emb, None)
             rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
+            if late_join is not None:
+                late_join.join(mesh_features)
         else:
             rgbd_features = self.feature_encoding_layer(rgbd_emb)
             rgbd_normalized = self.normalize_feature_layer(rgbd_features)
