@@ -186,7 +186,13 @@ class GeoMatch(nn.Module):
         emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
         if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
             # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
-            if settings.MESH_FORK_LATE:
+            if settings.MESH_ON_POINT_STREAM and isinstance(self.pcd_emb, FFB6DEmb) and settings.USE_TWO_STREAM_PIPELINE and "point" in settings.SIDE_PARTS:
+                # the mesh branch at the head of the POINT stream, in front of its wait for the pyramid (development switch)
+                box = []
+                rgbd_emb = self.pcd_emb(inputs, parts=heads is not None, side_first=lambda: box.append(self.mesh_features()))
+                mesh_features = box[0]
+                mesh_features.record_stream(torch.cuda.current_stream(rgb.device))
+            elif settings.MESH_FORK_LATE:
                 # enqueued BEHIND the embedding (it only waits for an event recorded before it): in a hipGraph the branch is still a
                 # root, but the executor -- which spreads a graph over very few hardware queues, in node order -- then keeps the image
                 # branch on a queue of its own instead of queueing layer1 behind the mesh kernels (tools/step_sequence.py, Queue_Id)
