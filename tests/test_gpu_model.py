@@ -442,16 +442,27 @@ def test_gpu_front_end_vs_synthetic_generator(golden_model):
     assert torch.isfinite(ep["rgbd"]).all() and ep["rgbd"].shape == (1, 128, N)
 
 
-def test_graphed_pipeline_equals_eager(golden_model):
-    """One hipGraph replay of pyramid + forward + matching + pose == the eager step on new inputs (bit-exact: the eval step has no float atomics)."""
-    from geometric_aware_dense_matching_amd import infer, matching, pose, pyramid
+@pytest.mark.parametrize("forked", [False, True])
+def test_graphed_pipeline_equals_eager(golden_model, forked):
+    """One hipGraph replay of pyramid + forward + matching + pose == the eager step on new inputs (bit-exact: the eval step has no float atomics).
+    forked: captured with settings.USE_SIDE_STREAMS (two-stream pipeline, mesh branch and pyramid on their own streams = parallel branches
+    of the graph) and replayed five times back to back; the reference is the single-stream eager step either way."""
+    from geometric_aware_dense_matching_amd import infer, matching, pose, pyramid, settings
     model, _ = golden_model
     b0 = _dev_inputs(synthetic.make_batch(seed=61, batch=2, n_points=1024))
     b0.pop("labels")
-    gp = infer.GraphedPipeline(model, b0)
-    b1 = _dev_inputs(synthetic.make_batch(seed=62, batch=2, n_points=1024))
-    b1.pop("labels")
-    got = {k: v.clone() for k, v in gp(b1).items()}
+    saved = settings.USE_SIDE_STREAMS
+    try:
+        settings.USE_SIDE_STREAMS = forked
+        gp = infer.GraphedPipeline(model, b0)
+        b1 = _dev_inputs(synthetic.make_batch(seed=62, batch=2, n_points=1024))
+        b1.pop("labels")
+        if forked:
+            for _ in range(4):
+                gp(b1)
+        got = {k: v.clone() for k, v in gp(b1).items()}
+    finally:
+        settings.USE_SIDE_STREAMS = saved
     d = dict(b1)
     d.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(d["cld_rgb_nrm"]), d["dpt_xyz"]))
     with torch.no_grad():
