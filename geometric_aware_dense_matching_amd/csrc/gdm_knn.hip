@@ -128,15 +128,27 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab
         }
         __syncthreads();
         const int steps = (npt + T - 1) >> logT;
+#ifndef GDM_K1P_NOUNROLL
 #pragma unroll 4
+#endif
         for (int s = 0; s < steps; ++s) {
             const int p = (s << logT) + t;
             const float4 v = tile[p];
+#ifdef GDM_K1P_SCALAR
+            knn_f32x2 r;
+            r.x = dist2_ref(qx.x, qy.x, qz.x, v.x, v.y, v.z);
+            r.y = dist2_ref(qx.y, qy.y, qz.y, v.x, v.y, v.z);
+#else
             const knn_f32x2 ex = qx - knn_f32x2{v.x, v.x}, ey = qy - knn_f32x2{v.y, v.y}, ez = qz - knn_f32x2{v.z, v.z};
             knn_f32x2 r = ex * ex;
             r = r + ey * ey;
             r = r + ez * ez;
+#endif
+#ifdef GDM_K1P_B128
+            const int pi = tile0 + p + (__float_as_int(v.w) & 0);          // keeps the fourth component (a 16-byte LDS read)
+#else
             const int pi = tile0 + p;
+#endif
             const bool c0 = r.x < d0, c1 = r.y < d1;              // strict: an equal distance has a larger index
             d0 = c0 ? r.x : d0; i0 = c0 ? pi : i0;
             d1 = c1 ? r.y : d1; i1 = c1 ? pi : i1;
@@ -774,7 +786,10 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     // default: correct in every ordered run (all parity tests), but in forked hipGraph replays launched back to back -- the pyramid on
     // its side stream beside the previous replay's model kernels -- a few K = 1 results per ~10 replays came out as if single support
     // points had been missing from the LDS tile (tools/diag_fork_race.py: 20-90 differing arrays in 40 rounds of 5 replays; 0 with
-    // knn_kernel<1>, 0 with a synchronize between replays).  The cause was not found in the round; the kernel stays for A/B.
+    // knn_kernel<1>, 0 with a synchronize between replays).  That was with the K = 1 launch directly behind the pyramid's first copy
+    // kernel; since the pyramid is built in two parts (the K = 1 launch now follows knn_wave_kernel and the second copy) the same
+    // stress shows 0 with this kernel too, in all of its variants (no unroll / scalar arithmetic / 16-byte LDS reads).  The cause was
+    // not found in the round, so the kernel stays opt-in.
     static int pair_env = -1;
     if (pair_env < 0) {
         const char* e = getenv("GDM_KNN1_PAIR");
