@@ -84,6 +84,7 @@ SIGNATURES = {
     "gdm_upconv_fused64_pack_weight_hip": (_i, [_vp, _vp, _vp]),
     "gdm_upconv_fused64_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "gdm_psp_combine_hip": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_psp_combine2_hip": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_gather_add_affine_act_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "gdm_conv1x1_gather_add_act_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_long, _i, _f, _vp, _vp]),
     "gdm_conv1x1_gather_add_act2_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_long, _i, _f, _i, _vp, _vp]),

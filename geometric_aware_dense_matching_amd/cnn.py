@@ -221,7 +221,7 @@ class PSPModule(nn.Module):
                     ys.append(ops.pointwise([p.reshape(B, Cin, s_ * s_)], mts[k]).view(B, -1, s_, s_))   # M_k . pool_k(f): own kernel
                 else:
                     ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
-            return ops.psp_combine(g, ys, self.bottleneck.bias)
+            return ops.psp_combine(g, ys, self.bottleneck.bias, packed=settings.USE_MFMA_GEMM)
         sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
         if (settings.USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
                 and (h * w) % 4 == 0 and feats.shape[0] * self.bottleneck.out_channels <= 65535 and h <= 64 and w <= 64):

@@ -669,6 +669,74 @@ __global__ __launch_bounds__(256) void psp_combine_kernel(const float* __restric
     }
 }
 
+// The same for EIGHT planes per workgroup (C % 8 == 0, W % 4 == 0): the interpolation coordinates of a pixel are computed once for its
+// eight channels, and the result is ALSO written as the packed split-bf16 operand of the next GEMM over the map (conv_pack_act_kernel's
+// layout: the eight channels of a pixel are one 16-byte group in the hi plane and one in the lo plane) -- the pack launch that followed
+// this kernel (33 us on the image branch's critical path) is gone.
+__global__ __launch_bounds__(256) void psp_combine8_kernel(const float* __restrict__ g, PspMaps maps, const float* __restrict__ bias,
+                                                           int C, int H, int W, float* __restrict__ out, unsigned char* __restrict__ ypk)
+{
+    const long plane0 = (long)blockIdx.y * 8;            // b * C + c0
+    const int b = (int)(plane0 / C), c0 = (int)(plane0 - (long)b * C);
+    const int hw = H * W;
+    __shared__ float pm[8][4][64];
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) {
+        const int j = i & 63, k = (i >> 6) & 3, ch = i >> 8;
+        const int ss = maps.s[k] * maps.s[k];
+        if (j < ss) pm[ch][k][j] = maps.y[k][(plane0 + ch) * ss + j];
+    }
+    __syncthreads();
+    float bc[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) bc[ch] = bias ? bias[c0 + ch] : 0.f;
+    const long pplane = (long)(H + 2) * (W + 2);
+    const int nchunk = (C + 127) / 128, chunk = c0 / 128, q = (c0 % 128) / 8;
+    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < hw; i0 += gridDim.x * 1024) {
+        const int oy = i0 / W, ox0 = i0 - oy * W;                      // four pixels of one row (W % 4 == 0)
+        float v[8][4];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + (plane0 + ch) * hw + i0);
+            v[ch][0] = gv.x + bc[ch]; v[ch][1] = gv.y + bc[ch]; v[ch][2] = gv.z + bc[ch]; v[ch][3] = gv.w + bc[ch];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = ox0 + e;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int S = maps.s[k];
+                const float fy = maps.sy[k] * (float)oy, fx = maps.sx[k] * (float)ox;
+                const int y0 = min((int)fy, S - 1), x0 = min((int)fx, S - 1);
+                const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+                const float ly = fy - (float)y0, lx = fx - (float)x0;
+                const int o00 = y0 * S + x0, o01 = y0 * S + x1, o10 = y1 * S + x0, o11 = y1 * S + x1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const float* m = &pm[ch][k][0];                     // the same expression, in the same order, as psp_combine_kernel
+                    v[ch][e] += (1.f - ly) * ((1.f - lx) * m[o00] + lx * m[o01]) + ly * ((1.f - lx) * m[o10] + lx * m[o11]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[ch][e] = fmaxf(v[ch][e], 0.f);
+            *reinterpret_cast<float4*>(out + (plane0 + ch) * hw + i0) = make_float4(v[ch][0], v[ch][1], v[ch][2], v[ch][3]);
+        }
+        if (ypk) {
+            unsigned char* o = ypk + ((((long)b * nchunk + chunk) * 32 + q) * pplane + (long)(oy + 1) * (W + 2) + ox0 + 1) * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gdm_split2(v[2 * i][e], v[2 * i + 1][e], hi[i], lo[i]);
+                *reinterpret_cast<uint4*>(o + e * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(o + e * 16 + 16 * pplane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
+        }
+    }
+}
+
 // y[b,c,j] = act(scale[c] * (x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]) : the point->pixel fusion layers
 // conv1x1(cat(rgb, nearest_interp(p))) + BN + ReLU (ffb6d.py:216-222,252-258) with the point half of the
 // convolution done at the (few) points and gathered afterwards (a 1x1 convolution commutes with a gather).
@@ -1031,8 +1099,19 @@ extern "C" int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Co
     return gdm_launch_status("upconv3x3_gather_bwd_kernel");
 }
 
+extern "C" int gdm_psp_combine2_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
+                                    const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* outpk,
+                                    void* stream);
+
 extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
                                    const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* stream)
+{
+    return gdm_psp_combine2_hip(g, y1, s1, y2, s2, y3, s3, y4, s4, bias, B, C, H, W, out, nullptr, stream);
+}
+
+extern "C" int gdm_psp_combine2_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
+                                    const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* outpk,
+                                    void* stream)
 {
     GDM_CHECK_ARG(g && y1 && y2 && y3 && y4 && out, "gdm_psp_combine_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && C >= 1 && (long)B * C <= 65535 && H >= 1 && W >= 1 && s1 >= 1 && s2 >= 1 && s3 >= 1 && s4 >= 1,
@@ -1048,6 +1127,13 @@ extern "C" int gdm_psp_combine_hip(const float* g, const float* y1, int s1, cons
     GDM_CHECK_ARG(((long)H * W) % 4 == 0 && (((uintptr_t)g | (uintptr_t)out) & 15) == 0, "gdm_psp_combine_hip: H*W must be a multiple of 4 and the maps 16-byte aligned");
     int gx = gdm_cdiv((long)H * W, 1024);
     if (gx > 16) gx = 16;
+    if (outpk) {
+        GDM_CHECK_ARG(C % 8 == 0 && W % 4 == 0 && ((uintptr_t)outpk & 15) == 0 && (C == 64 || C % 128 == 0),
+                      "gdm_psp_combine2_hip: packed output needs C = 64 or a multiple of 128 and W %% 4 == 0 (C=%d W=%d)", C, W);
+        hipLaunchKernelGGL(psp_combine8_kernel, dim3(gx, B * C / 8), dim3(256), 0, (hipStream_t)stream, g, maps, bias, C, H, W, out,
+                           (unsigned char*)outpk);
+        return gdm_launch_status("psp_combine8_kernel");
+    }
     hipLaunchKernelGGL(psp_combine_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, g, maps, bias, C, H, W, out);
     return gdm_launch_status("psp_combine_kernel");
 }

@@ -1013,16 +1013,23 @@ def upconv_train_supported(B, cout):
     return B * 9 * cout <= 65535
 
 
-def psp_combine(g, ys, bias):
-    """out = relu(g + bias + sum_k bilinear_up(ys[k])); g f32[B,C,H,W], ys four f32[B,C,s,s].  Inference only, in place on g."""
+def psp_combine(g, ys, bias, packed=False):
+    """out = relu(g + bias + sum_k bilinear_up(ys[k])); g f32[B,C,H,W], ys four f32[B,C,s,s].  Inference only, in place on g.
+    packed: the kernel also writes the packed split-bf16 operand of the GEMMs that read the map next (hung on the result as
+    `_gdm_packed`, see gemm_bf16x3_map) -- no pack launch in front of them."""
     g = _dev(g, torch.float32, "g")
     B, C, H, W = g.shape
     ys = [_dev(y, torch.float32, "y") for y in ys]
     assert len(ys) == 4
-    check(_lib.lib().gdm_psp_combine_hip(g.data_ptr(), ys[0].data_ptr(), ys[0].shape[2], ys[1].data_ptr(), ys[1].shape[2],
-                                         ys[2].data_ptr(), ys[2].shape[2], ys[3].data_ptr(), ys[3].shape[2],
-                                         bias.data_ptr() if bias is not None else None, B, C, H, W, g.data_ptr(), _stream()),
-          "gdm_psp_combine_hip")
+    opk = None
+    if packed and (C == 64 or C % 128 == 0) and W % 32 == 0 and (B * H * W) % 256 == 0 and B * C // 8 <= 65535:
+        opk = PackedAct(_packed_buffer(B, C, H, W, g.device), (B, C, H, W))
+    check(_lib.lib().gdm_psp_combine2_hip(g.data_ptr(), ys[0].data_ptr(), ys[0].shape[2], ys[1].data_ptr(), ys[1].shape[2],
+                                          ys[2].data_ptr(), ys[2].shape[2], ys[3].data_ptr(), ys[3].shape[2],
+                                          bias.data_ptr() if bias is not None else None, B, C, H, W, g.data_ptr(),
+                                          opk.buf.data_ptr() if opk is not None else None, _stream()), "gdm_psp_combine2_hip")
+    if opk is not None:
+        g._gdm_packed = opk
     return g
 
 

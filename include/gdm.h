@@ -339,6 +339,10 @@ int gdm_upconv_fused64_hip(const float* x, const void* wpk, const float* scale, 
  * out = relu(g + bias[c] + sum_k bilinear_align_corners(y_k)), g f32[B,C,H,W] = W_f . feats, y_k f32[B,C,s_k,s_k] = W_k . prior_k. */
 int gdm_psp_combine_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
                         const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* stream);
+/* The same, also writing the result as the packed split-bf16 operand (gdm_conv3x3_pack_act_hip's layout, gdm_conv3x3_act_bytes bytes, zero
+ * border kept by the caller) of the next GEMM over the map: C = 64 or a multiple of 128, W % 4 == 0.  outpk NULL = gdm_psp_combine_hip. */
+int gdm_psp_combine2_hip(const float* g, const float* y1, int s1, const float* y2, int s2, const float* y3, int s3,
+                         const float* y4, int s4, const float* bias, int B, int C, int H, int W, float* out, void* outpk, void* stream);
 /* Point->pixel fusion tail (ffb6d.py:216-222,252-258): y[b,c,j] = act(scale[c]*(x[b,c,j] + t[b,c,idx[b,j]]) + shift[c]),
  * x f32[B,C,m] (pixel half of the 1x1 conv), t f32[B,C,n] (point half, computed at the points), idx i32[B,m]. May run in place. */
 int gdm_gather_add_affine_act_hip(const float* x, const float* t, const int32_t* idx, const float* scale, const float* shift,

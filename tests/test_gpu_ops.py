@@ -783,3 +783,30 @@ def test_stem_kernel_vs_torch_fp64(ops, B, H, W):
         assert torch.equal(ref.buf, mine)
     else:
         assert pk is None
+
+
+@pytest.mark.parametrize("B,C,H,W", [(16, 1024, 32, 32), (2, 128, 32, 32), (1, 64, 16, 32), (3, 24, 10, 12)])
+def test_psp_combine_with_packed_output(ops, B, C, H, W):
+    """psp_combine (pspnet.py:24-31 without the 2560-channel concat): the eight-planes-per-workgroup form that also writes the packed
+    operand == the one-plane form bit for bit (same expression, same order), == relu(g + bias + sum of align_corners interpolations)
+    in fp64; its packed operand is byte-identical to what the pack kernel makes of the fp32 result."""
+    g0 = torch.Generator(device="cpu").manual_seed(C + H)
+    g = torch.randn(B, C, H, W, generator=g0).cuda()
+    ys = [torch.randn(B, C, s, s, generator=g0).cuda() for s in (1, 2, 3, 6)]
+    bias = torch.randn(C, generator=g0).cuda()
+    plain = ops.psp_combine(g.clone(), ys, bias)
+    assert getattr(plain, "_gdm_packed", None) is None
+    want = g.double() + bias.double().view(1, -1, 1, 1)
+    for y in ys:
+        want = want + torch.nn.functional.interpolate(y.double(), size=(H, W), mode="bilinear", align_corners=True)
+    want = torch.relu(want)
+    assert (plain.double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    got = ops.psp_combine(g.clone(), ys, bias, packed=True)
+    assert torch.equal(got, plain)
+    pk = getattr(got, "_gdm_packed", None)
+    if (C == 64 or C % 128 == 0) and W % 32 == 0 and (B * H * W) % 256 == 0:
+        assert pk is not None and pk.shape == (B, C, H, W)
+        mine = pk.buf.clone()
+        assert torch.equal(ops.conv3x3_pack_act(got.clone()).buf, mine)
+    else:
+        assert pk is None
