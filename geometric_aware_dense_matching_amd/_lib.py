@@ -79,6 +79,7 @@ SIGNATURES = {
     "gdm_prelu1_hip": (_i, [_vp, _vp, ctypes.c_long, _vp, _vp]),
     "gdm_prelu1_bwd_hip": (_i, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _vp]),
     "gdm_upconv3x3_gather_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "gdm_upconv3x3_gather2_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gdm_upconv3x3_gather_bwd_hip": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_upconv_fused64_weight_bytes": (_sz, []),
     "gdm_upconv_fused64_pack_weight_hip": (_i, [_vp, _vp, _vp]),

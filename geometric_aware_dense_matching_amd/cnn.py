@@ -221,7 +221,7 @@ class PSPModule(nn.Module):
                     ys.append(ops.pointwise([p.reshape(B, Cin, s_ * s_)], mts[k]).view(B, -1, s_, s_))   # M_k . pool_k(f): own kernel
                 else:
                     ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
-            return ops.psp_combine(g, ys, self.bottleneck.bias, packed=settings.USE_MFMA_GEMM)
+            return ops.psp_combine(g, ys, self.bottleneck.bias, packed=settings.USE_MFMA_GEMM and settings.USE_PACKED_PRODUCERS)
         sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
         if (settings.USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)
                 and (h * w) % 4 == 0 and feats.shape[0] * self.bottleneck.out_channels <= 65535 and h <= 64 and w <= 64):
@@ -290,7 +290,9 @@ class PSPUpsample(nn.Module):
                 else:
                     z = ops.wx(self._tap_major_weight(), x.reshape(Bx, Cin, Hx * Wx)).view(Bx, -1, Hx, Wx)   # hipBLASLt GEMM
                 scale, shift = folded_bn(self.conv[2], conv.bias)
-                return ops.upconv3x3_gather(z, scale, shift, conv.out_channels, (x.shape[2] * 2, x.shape[3] * 2), code[0], code[1])
+                # >= 128 channels: the next reader is a GEMM over the map (the p2r fusion's pixel half), so the gather writes its operand
+                return ops.upconv3x3_gather(z, scale, shift, conv.out_channels, (x.shape[2] * 2, x.shape[3] * 2), code[0], code[1],
+                                            packed=settings.USE_MFMA_GEMM and settings.USE_PACKED_PRODUCERS and conv.out_channels % 128 == 0)
         act = self.conv[3]
         if x.is_cuda and isinstance(act, nn.PReLU) and act.weight.numel() == 1 and x.dtype == torch.float32:
             conv = self.conv[1]

@@ -612,6 +612,102 @@ __global__ __launch_bounds__(256) void upconv3x3_gather_lds_kernel(const float* 
     }
 }
 
+// EIGHT output channels per workgroup (Cout % 8 == 0): a 32 x 8 output tile, thread = one output pixel, the interpolation
+// coefficients of a pixel computed once for its eight channels (the one-channel form above is VALU-bound on exactly those), and the
+// result ALSO written as the packed split-bf16 operand of the next GEMM over the map (conv_pack_act_kernel's layout: the eight channels
+// of a pixel = one 16-byte group in the hi plane and one in the lo plane): the pack launch that followed (36 us in front of the p2r GEMM
+// of the first up stage, on the image branch's critical path) is gone.  Same taps, same blend expression, same order: same bits.
+constexpr int U8_W = 32, U8_H = 8, U8_PH = 8, U8_PW = 20;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void upconv3x3_gather8_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int Cout, int H, int W, int OH, int OW,
+                                                                float rh, float rw, float slope, float* __restrict__ out,
+                                                                unsigned char* __restrict__ ypk)
+{
+    // the eight channels in two passes of four: 28 KB of LDS per workgroup (five workgroups per CU) instead of 57 KB (two)
+    __shared__ float patch[4][9][U8_PH + 1][U8_PW + 2];
+    const int groups = Cout / 8;
+    const int b = blockIdx.z / groups, c0 = (blockIdx.z - b * groups) * 8;
+    const int ox_t = blockIdx.x * U8_W, oy_t = blockIdx.y * U8_H;
+    const int ys0 = min((int)(rh * (float)max(oy_t - 1, 0)), H - 1);
+    const int ys1 = min((int)(rh * (float)min(oy_t + U8_H, OH - 1)) + 1, H - 1);
+    const int xs0 = min((int)(rw * (float)max(ox_t - 1, 0)), W - 1);
+    const int xs1 = min((int)(rw * (float)min(ox_t + U8_W, OW - 1)) + 1, W - 1);
+    const int ph = ys1 - ys0 + 2, pw = xs1 - xs0 + 2;
+    const long plane_sz = (long)H * W;
+    const unsigned inv_pw = ((1u << 20) + pw - 1) / pw;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int oy = oy_t + ty, ox = ox_t + tx;
+    const bool live = oy < OH && ox < OW;
+    float acc[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) acc[ch] = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* zb = z + ((long)b * 9 * Cout + c0 + 4 * pass) * plane_sz;
+        if (pass) __syncthreads();                                  // the first four channels' patch has been read
+        for (int i = threadIdx.x; i < ph * pw; i += 256) {
+            const int r = (int)(((unsigned)i * inv_pw) >> 20);
+            const int c = i - r * pw;
+            const float* src = zb + (long)min(ys0 + r, H - 1) * W + min(xs0 + c, W - 1);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) patch[ch][tap][r][c] = src[((long)tap * Cout + ch) * plane_sz];
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = oy + dy;
+                if (yy < 0 || yy >= OH) continue;
+                const float sy = rh * (float)yy;
+                const int y0 = min((int)sy, H - 1);
+                const float ly = sy - (float)y0, hy = 1.f - ly;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = ox + dx;
+                    if (xx < 0 || xx >= OW) continue;
+                    const int tap = (dy + 1) * 3 + (dx + 1);
+                    const float sx = rw * (float)xx;
+                    const int x0 = min((int)sx, W - 1);
+                    const float lx = sx - (float)x0, hx = 1.f - lx;
+                    const int xo = x0 - xs0, yo = y0 - ys0;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const float* r0 = &patch[ch][tap][yo][0];
+                        const float* r1 = r0 + (U8_PW + 2);
+                        const float top = fmaf(lx, r0[xo + 1], hx * r0[xo]);
+                        const float bot = fmaf(lx, r1[xo + 1], hx * r1[xo]);
+                        acc[4 * pass + ch] = fmaf(ly, bot, fmaf(hy, top, acc[4 * pass + ch]));
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    float v[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        float o = acc[ch] * scale[c0 + ch] + shift[c0 + ch];
+        if (ACT == 1) o = fmaxf(o, 0.f);
+        if (ACT == 2) o = o > 0.f ? o : o * slope;
+        v[ch] = o;
+        out[(((long)b * Cout + c0 + ch) * OH + oy) * OW + ox] = o;
+    }
+    if (ypk) {
+        const long pplane = (long)(OH + 2) * (OW + 2);
+        const int nchunk = (Cout + 127) / 128, chunk = c0 / 128, q = (c0 % 128) / 8;
+        unsigned char* o = ypk + ((((long)b * nchunk + chunk) * 32 + q) * pplane + (long)(oy + 1) * (OW + 2) + ox + 1) * 16;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gdm_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+        *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + 16 * pplane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 // Pyramid-pooling bottleneck without the 2560-channel concat (pspnet.py:24-31):
 //   relu(W . cat(up(p1), up(p2), up(p3), up(p6), f) + b) = relu(W_f f + b + sum_s up(W_s p_s))
 // (1x1 convolution commutes with bilinear interpolation).  g = W_f f is a GEMM with K = 512 instead of 2560;
@@ -1057,6 +1153,25 @@ extern "C" int gdm_affine_act_hip(const float* x, const float* scale, const floa
     else { if (!has) AA(2, false, false); else if (aff) AA(2, true, true); else AA(2, true, false); }
 #undef AA
     return gdm_launch_status("affine_act_kernel");
+}
+
+extern "C" int gdm_upconv3x3_gather2_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
+                                         int OH, int OW, int act, float slope, float* out, void* outpk, void* stream)
+{
+    GDM_CHECK_ARG(z && scale && shift && out && outpk, "gdm_upconv3x3_gather2_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && Cout >= 8 && Cout % 8 == 0 && (Cout == 64 || Cout % 128 == 0) && (long)B * (Cout / 8) <= 65535 && H >= 1 && W >= 1
+                  && OH >= 1 && OW >= 1, "gdm_upconv3x3_gather2_hip: bad shape B=%d Cout=%d %dx%d -> %dx%d (Cout = 64 or a multiple of 128)",
+                  B, Cout, H, W, OH, OW);
+    GDM_CHECK_ARG(act >= 0 && act <= 2 && ((uintptr_t)outpk & 15) == 0, "gdm_upconv3x3_gather2_hip: act=%d / unaligned packed output", act);
+    const float rh = scale_ac(H, OH), rw = scale_ac(W, OW);
+    GDM_CHECK_ARG((int)(rh * (U8_H + 1)) + 3 <= U8_PH && (int)(rw * (U8_W + 1)) + 3 <= U8_PW,
+                  "gdm_upconv3x3_gather2_hip: scale factors %g x %g too large for the LDS tile (the x2 stages of PSPUpsample fit)", rh, rw);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(gdm_cdiv(OW, U8_W), gdm_cdiv(OH, U8_H), B * (Cout / 8));
+    if (act == 0) hipLaunchKernelGGL(upconv3x3_gather8_kernel<0>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out, (unsigned char*)outpk);
+    else if (act == 1) hipLaunchKernelGGL(upconv3x3_gather8_kernel<1>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out, (unsigned char*)outpk);
+    else hipLaunchKernelGGL(upconv3x3_gather8_kernel<2>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out, (unsigned char*)outpk);
+    return gdm_launch_status("upconv3x3_gather8_kernel");
 }
 
 extern "C" int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,

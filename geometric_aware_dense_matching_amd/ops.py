@@ -757,14 +757,22 @@ def batch_norm_act_train(x, bn, act=ACT_NONE, slope=0.0):
     return y
 
 
-def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0):
+def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0, packed=False):
     """z f32[B, 9*cout, H, W] (low-resolution tap-major channel mixes) -> f32[B, cout, OH, OW]: the 9-tap bilinear
-    gather that completes conv3x3(upsample(x)) + folded BN + activation.  Inference only."""
+    gather that completes conv3x3(upsample(x)) + folded BN + activation.  Inference only.  packed: the eight-channel form, which also
+    writes the packed split-bf16 operand of the GEMM that reads the map next (hung on the result as `_gdm_packed`)."""
     z = _dev(z, torch.float32, "z")
     B, c9, H, W = z.shape
     assert c9 == 9 * cout
     OH, OW = int(out_size[0]), int(out_size[1])
     out = torch.empty((B, cout, OH, OW), dtype=torch.float32, device=z.device)
+    if (packed and (cout == 64 or cout % 128 == 0) and OW % 32 == 0 and (B * OH * OW) % 256 == 0 and B * cout // 8 <= 65535
+            and (OH, OW) == (2 * H, 2 * W)):
+        opk = PackedAct(_packed_buffer(B, cout, OH, OW, z.device), (B, cout, OH, OW))
+        check(_lib.lib().gdm_upconv3x3_gather2_hip(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, cout, H, W, OH, OW, act,
+                                                   float(slope), out.data_ptr(), opk.buf.data_ptr(), _stream()), "gdm_upconv3x3_gather2_hip")
+        out._gdm_packed = opk
+        return out
     check(_lib.lib().gdm_upconv3x3_gather_hip(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, cout, H, W, OH, OW, act,
                                               float(slope), out.data_ptr(), _stream()), "gdm_upconv3x3_gather_hip")
     return out

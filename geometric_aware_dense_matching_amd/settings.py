@@ -66,6 +66,7 @@ USE_MFMA_GEMM_TRAIN = _flag("GDM_MFMA_GEMM_TRAIN")
 USE_GATHERED_FINAL = _flag("GDM_GATHERED_FINAL")
 USE_DIRECT_WGRAD = _flag("GDM_DIRECT_WGRAD")
 USE_FUSED_ADAM = _flag("GDM_FUSED_ADAM")
+USE_PACKED_PRODUCERS = _flag("GDM_PACKED_PRODUCERS")     # psp_combine / the up-conv gather write the next GEMM's packed operand themselves
 USE_TWO_STREAM_PIPELINE = _flag("GDM_TWO_STREAM_PIPELINE")     # with USE_SIDE_STREAMS: image / point streams run ahead of each other, one event per stage and direction
 MESH_FORK_LATE = os.environ.get("GDM_MESH_FORK_LATE", "1") != "0"       # with USE_SIDE_STREAMS: the mesh fork is enqueued behind the embedding
 MESH_ON_POINT_STREAM = os.environ.get("GDM_MESH_ON_POINT_STREAM", "0") == "1"   # development: the mesh branch at the head of the point stream

@@ -324,6 +324,10 @@ int gdm_affine_act_hip(const float* x, const float* scale, const float* shift, c
  * activation (0 none, 1 ReLU, 2 leaky/PReLU slope) -> out f32[B, Cout, OH, OW].                              */
 int gdm_upconv3x3_gather_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
                              int OH, int OW, int act, float slope, float* out, void* stream);
+/* The same with eight output channels per workgroup, also writing the result as the packed split-bf16 operand (gdm_conv3x3_act_bytes
+ * (B, Cout, OH, OW) bytes, zero border kept by the caller) of the next GEMM over the map: Cout = 64 or a multiple of 128, x2 stages. */
+int gdm_upconv3x3_gather2_hip(const float* z, const float* scale, const float* shift, int B, int Cout, int H, int W,
+                              int OH, int OW, int act, float slope, float* out, void* outpk, void* stream);
 /* Its transpose for training (scale = 1, act = none): grad_z f32[B,9*Cout,H,W] from grad_out f32[B,Cout,OH,OW]; every element of
  * grad_z is written (gather form, no atomics).  B*9*Cout <= 65535. */
 int gdm_upconv3x3_gather_bwd_hip(const float* grad_out, int B, int Cout, int H, int W, int OH, int OW, float* grad_z, void* stream);

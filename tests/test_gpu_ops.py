@@ -810,3 +810,24 @@ def test_psp_combine_with_packed_output(ops, B, C, H, W):
         assert torch.equal(ops.conv3x3_pack_act(got.clone()).buf, mine)
     else:
         assert pk is None
+
+
+@pytest.mark.parametrize("B,C,H,W,act", [(16, 256, 32, 32, 2), (2, 128, 16, 16, 1), (1, 64, 16, 32, 0)])
+def test_upconv_gather_eight_channel_form_with_packed_output(ops, B, C, H, W, act):
+    """upconv3x3_gather (the 9-tap bilinear gather that completes conv3x3(upsample x2) + BN + activation, pspnet.py:34-45): the
+    eight-channels-per-workgroup form == the one-channel form bit for bit, and its packed operand is byte-identical to what the pack
+    kernel makes of the fp32 result."""
+    g0 = torch.Generator(device="cpu").manual_seed(C + H + act)
+    z = torch.randn(B, 9 * C, H, W, generator=g0).cuda()
+    scale, shift = (torch.rand(C, generator=g0) + 0.5).cuda(), (torch.randn(C, generator=g0) * 0.3).cuda()
+    plain = ops.upconv3x3_gather(z, scale, shift, C, (2 * H, 2 * W), act, 0.25)
+    got = ops.upconv3x3_gather(z, scale, shift, C, (2 * H, 2 * W), act, 0.25, packed=True)
+    assert getattr(plain, "_gdm_packed", None) is None
+    assert torch.equal(got, plain)
+    pk = getattr(got, "_gdm_packed", None)
+    if (2 * W) % 32 == 0 and (B * 4 * H * W) % 256 == 0:
+        assert pk is not None and pk.shape == (B, C, 2 * H, 2 * W)
+        mine = pk.buf.clone()
+        assert torch.equal(ops.conv3x3_pack_act(got.clone()).buf, mine)
+    else:
+        assert pk is None
