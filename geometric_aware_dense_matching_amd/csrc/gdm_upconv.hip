@@ -590,7 +590,10 @@ template <int ACT, bool PM, bool TPM>
 __global__ __launch_bounds__(256, 4) void conv64_gather_add_act_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
                                                                           const float* __restrict__ t, const int32_t* __restrict__ idx,
                                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                          int n, int m, float slope, float* __restrict__ y)
+                                                                          int n, int m, float slope, float* __restrict__ y,
+                                                                          // optional (NCHW form): the result also as the packed split-bf16
+                                                                          // operand of the next convolution over the [B, 64, m / W, W] map
+                                                                          unsigned char* __restrict__ ypk = nullptr, int W = 0)
 {
     __shared__ __attribute__((aligned(16))) unsigned char rows[CG_P * UF_ROWB];      // 16 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -672,7 +675,6 @@ __global__ __launch_bounds__(256, 4) void conv64_gather_add_act_mfma_kernel(cons
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
         const int j = j0 + 16 * pb + l16;
-        if (j >= m) continue;
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -681,6 +683,24 @@ __global__ __launch_bounds__(256, 4) void conv64_gather_add_act_mfma_kernel(cons
             if (ACT == 2) v = v > 0.f ? v : v * slope;
             o[r] = v;
         }
+        if (!PM && ypk) {
+            // lanes kg and kg ^ 1 hold the two halves of an 8-channel group of this pixel: the even one writes the 16-byte granules
+            float p4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = __shfl_xor(o[r], 16);
+            if (j < m && !(kg & 1)) {
+                const int H = m / W, yy = j / W, xx = j - yy * W;
+                const long plane = (long)(H + 2) * (W + 2);
+                const int q = 2 * wave + (kg >> 1);
+                unsigned char* op = ypk + ((((long)b * 32) + q) * plane + (long)(yy + 1) * (W + 2) + xx + 1) * 16;
+                unsigned hi[4], lo[4];
+                gdm_split2(o[0], o[1], hi[0], lo[0]); gdm_split2(o[2], o[3], hi[1], lo[1]);
+                gdm_split2(p4[0], p4[1], hi[2], lo[2]); gdm_split2(p4[2], p4[3], hi[3], lo[3]);
+                *reinterpret_cast<uint4*>(op) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(op + 16 * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
+        }
+        if (j >= m) continue;
         if (PM) {
             *reinterpret_cast<float4*>(y + ((long)b * m + j) * UF_C + c0) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -787,15 +807,29 @@ extern "C" int gdm_upconv_final_points_hip(const float* xpm, const int32_t* choo
     return gdm_launch_status("upconv_final_points_kernel");
 }
 
+extern "C" int gdm_conv64_gather_add_act_mfma2_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
+                                                   const float* shift, int B, int n, long m, int act, float slope, int pixel_major,
+                                                   int t_point_major, float* y, void* ypk, int W, void* stream);
+
 extern "C" int gdm_conv64_gather_add_act_mfma_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
                                                   const float* shift, int B, int n, long m, int act, float slope, int pixel_major,
                                                   int t_point_major, float* y, void* stream)
 {
+    return gdm_conv64_gather_add_act_mfma2_hip(x, wpk, t, idx, scale, shift, B, n, m, act, slope, pixel_major, t_point_major, y, nullptr, 0, stream);
+}
+
+extern "C" int gdm_conv64_gather_add_act_mfma2_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
+                                                   const float* shift, int B, int n, long m, int act, float slope, int pixel_major,
+                                                   int t_point_major, float* y, void* ypk, int W, void* stream)
+{
     GDM_CHECK_ARG(x && wpk && t && idx && scale && shift && y, "gdm_conv64_gather_add_act_mfma_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1 && m >= 1 && m <= 0x7fffffffL && act >= 0 && act <= 2, "gdm_conv64_gather_add_act_mfma_hip: bad shape");
+    GDM_CHECK_ARG(!ypk || (!pixel_major && W >= 1 && m % W == 0 && ((uintptr_t)ypk & 15) == 0),
+                  "gdm_conv64_gather_add_act_mfma2_hip: packed output goes with the NCHW form of an [m / W, W] map (m=%ld W=%d)", m, W);
+    unsigned char* ypk8 = (unsigned char*)ypk;
     dim3 grid(gdm_cdiv(m, CG_P), B);
     hipStream_t s = (hipStream_t)stream;
-#define CGM(A, P, T) hipLaunchKernelGGL((conv64_gather_add_act_mfma_kernel<A, P, T>), grid, dim3(256), 0, s, x, (const unsigned char*)wpk, t, idx, scale, shift, n, (int)m, slope, y)
+#define CGM(A, P, T) hipLaunchKernelGGL((conv64_gather_add_act_mfma_kernel<A, P, T>), grid, dim3(256), 0, s, x, (const unsigned char*)wpk, t, idx, scale, shift, n, (int)m, slope, y, ypk8, W)
 #define CGA(A) do { if (pixel_major) { if (t_point_major) CGM(A, true, true); else CGM(A, true, false); } \
                     else { if (t_point_major) CGM(A, false, true); else CGM(A, false, false); } } while (0)
     if (act == 0) CGA(0); else if (act == 1) CGA(1); else CGA(2);

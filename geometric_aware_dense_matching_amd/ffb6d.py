@@ -133,7 +133,7 @@ class FFB6DEmb(nn.Module):
             return ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"), point_major=True)       # [B, n', 64]
         return ops.pointwise([pp], self._fuse_weight_t(fuse_layer, wb, "b"))                             # [B, Cout, n']
 
-    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False, point_term=None):
+    def _p2r_fuse(self, pre_layer, fuse_layer, rgb_emb0, p_emb0, idx, pixel_major=False, point_term=None, want_packed=False):
         """fuse(cat(rgb_emb0, nearest_interp(pre(p_emb0)))) (ffb6d.py:216-222,252-258).  Eval: the point half of the
         1x1 fuse convolution runs at the points (a 1x1 conv commutes with the gather), the pixel half is a GEMM with half
         the K, and gather + add + BN + ReLU is one HIP launch; no concat, no full-resolution point features."""
@@ -160,8 +160,14 @@ class FFB6DEmb(nn.Module):
                         cache = (wa, ops.pack_rows64(wa))
                         fuse_layer.__dict__["_gdm_wa_pk"] = cache
                     y = ops.conv64_gather_add_act_mfma(rgb_emb0.reshape(bs, c, hr * wr), cache[1], t_pm, idx.reshape(bs, -1), scale, shift,
-                                                       code[0], code[1], pixel_major=pixel_major, t_point_major=True)
-                    return y if pixel_major else y.view(bs, -1, hr, wr)
+                                                       code[0], code[1], pixel_major=pixel_major, t_point_major=True,
+                                                       hw=(hr, wr) if (want_packed and settings.USE_PACKED_PRODUCERS and not pixel_major) else None)
+                    if pixel_major:
+                        return y
+                    out = y.view(bs, -1, hr, wr)
+                    if getattr(y, "_gdm_packed", None) is not None:
+                        out._gdm_packed = y._gdm_packed         # the next stage's first convolution reads this: no pack launch
+                    return out
                 if point_term is not None:
                     t = point_term
                 else:
@@ -259,7 +265,7 @@ class FFB6DEmb(nn.Module):
                 ds_emb.append(f_encoder_i)
 
             rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,
-                                     inputs["p2r_ds_nei_idx%d" % i_ds])
+                                     inputs["p2r_ds_nei_idx%d" % i_ds], want_packed=True)
 
             r2p_emb = self.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs["r2p_ds_nei_idx%d" % i_ds])
             r2p_emb = self.ds_fuse_r2p_pre_layers[i_ds](r2p_emb)
@@ -361,7 +367,7 @@ class FFB6DEmb(nn.Module):
             M.wait_event(ev_p0)
             to(M, p_emb0, pt)
             rgb_emb = self._p2r_fuse(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], rgb_emb0, p_emb0,
-                                     inputs["p2r_ds_nei_idx%d" % i_ds], point_term=pt)
+                                     inputs["p2r_ds_nei_idx%d" % i_ds], point_term=pt, want_packed=True)
         n_up = len(self.rndla_up_stages)
         sparse_final = self._sparse_final_ok(inputs["rgb"])
         for i_up in range(n_up - 1):

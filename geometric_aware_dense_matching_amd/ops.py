@@ -1082,9 +1082,10 @@ def lfa_supported(d_out, K):
     return K == 16 and d_out in (32, 64, 128, 256)
 
 
-def conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act=ACT_NONE, slope=0.0, pixel_major=False, t_point_major=False):
+def conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act=ACT_NONE, slope=0.0, pixel_major=False, t_point_major=False, hw=None):
     """conv1x1_gather_add_act with the 64 x 64 channel mix on split-bf16 MFMA: wpk = pack_rows64(W[64,64]) (row = output channel).
-    t f32[B,64,n], or f32[B,n,64] with t_point_major (the gathered term is then one contiguous row per pixel).  Inference only."""
+    t f32[B,64,n], or f32[B,n,64] with t_point_major (the gathered term is then one contiguous row per pixel).  Inference only.
+    hw = (H, W) of the pixel map (NCHW form): the kernel also writes the packed operand of the next convolution (`_gdm_packed`)."""
     x = _dev(x, torch.float32, "x")
     t = _dev(t, torch.float32, "t")
     idx = _idx32(idx, "idx")
@@ -1093,9 +1094,15 @@ def conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act=ACT_NONE, slope
     if C != 64 or t.shape[2 if t_point_major else 1] != 64 or wpk.numel() != 64 * 256:
         raise ValueError("conv64_gather_add_act_mfma: built for 64 -> 64 channels, got x %s t %s" % (tuple(x.shape), tuple(t.shape)))
     y = torch.empty((B, m, C), dtype=torch.float32, device=x.device) if pixel_major else torch.empty_like(x)
-    check(_lib.lib().gdm_conv64_gather_add_act_mfma_hip(x.data_ptr(), wpk.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
-                                                        shift.data_ptr(), B, n, m, act, float(slope), int(bool(pixel_major)),
-                                                        int(bool(t_point_major)), y.data_ptr(), _stream()), "gdm_conv64_gather_add_act_mfma_hip")
+    opk = None
+    if hw is not None and not pixel_major and hw[0] * hw[1] == m and hw[1] % 32 == 0 and (B * m) % 256 == 0:
+        opk = PackedAct(_packed_buffer(B, C, hw[0], hw[1], x.device), (B, C, hw[0], hw[1]))
+    check(_lib.lib().gdm_conv64_gather_add_act_mfma2_hip(x.data_ptr(), wpk.data_ptr(), t.data_ptr(), idx.data_ptr(), scale.data_ptr(),
+                                                         shift.data_ptr(), B, n, m, act, float(slope), int(bool(pixel_major)),
+                                                         int(bool(t_point_major)), y.data_ptr(), opk.buf.data_ptr() if opk is not None else None,
+                                                         int(hw[1]) if opk is not None else 0, _stream()), "gdm_conv64_gather_add_act_mfma2_hip")
+    if opk is not None:
+        y._gdm_packed = opk
     return y
 
 

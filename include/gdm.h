@@ -365,6 +365,11 @@ int gdm_conv1x1_gather_add_act_hip(const float* x, const float* wt, const float*
 int gdm_conv64_gather_add_act_mfma_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
                                        const float* shift, int B, int n, long m, int act, float slope, int pixel_major, int t_point_major,
                                        float* y, void* stream);
+/* The same (NCHW form) also writing the result as the packed split-bf16 operand of the next convolution over the [B, 64, m / W, W] map
+ * (gdm_conv3x3_act_bytes(B, 64, m / W, W) bytes, zero border kept by the caller).  ypk NULL = gdm_conv64_gather_add_act_mfma_hip. */
+int gdm_conv64_gather_add_act_mfma2_hip(const float* x, const void* wpk, const float* t, const int32_t* idx, const float* scale,
+                                        const float* shift, int B, int n, long m, int act, float slope, int pixel_major,
+                                        int t_point_major, float* y, void* ypk, int W, void* stream);
 /* The same with the output layout selectable: pixel_major != 0 writes y f32[B, m, C] (one 256-byte row per pixel). */
 int gdm_conv1x1_gather_add_act2_hip(const float* x, const float* wt, const float* t, const int32_t* idx, const float* scale,
                                     const float* shift, int B, int C, int n, long m, int act, float slope, int pixel_major,

@@ -831,3 +831,22 @@ def test_upconv_gather_eight_channel_form_with_packed_output(ops, B, C, H, W, ac
         assert torch.equal(ops.conv3x3_pack_act(got.clone()).buf, mine)
     else:
         assert pk is None
+
+
+@pytest.mark.parametrize("B,H,W,n,act", [(16, 64, 64, 512, 1), (2, 8, 32, 100, 2)])
+def test_conv64_fusion_kernel_packed_output(ops, B, H, W, n, act):
+    """conv64_gather_add_act_mfma with hw: same fp32 result as without, and a packed operand byte-identical to the pack kernel's."""
+    g0 = torch.Generator(device="cpu").manual_seed(H + n)
+    m = H * W
+    x = torch.randn(B, 64, m, generator=g0).cuda()
+    wpk = ops.pack_rows64((torch.randn(64, 64, generator=g0) / 8).cuda())
+    t = torch.randn(B, n, 64, generator=g0).cuda()
+    idx = torch.randint(0, n, (B, m), generator=g0, dtype=torch.int32).cuda()
+    scale, shift = (torch.rand(64, generator=g0) + 0.5).cuda(), (torch.randn(64, generator=g0) * 0.3).cuda()
+    plain = ops.conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act, 0.2, t_point_major=True)
+    got = ops.conv64_gather_add_act_mfma(x, wpk, t, idx, scale, shift, act, 0.2, t_point_major=True, hw=(H, W))
+    assert torch.equal(got, plain)
+    pk = getattr(got, "_gdm_packed", None)
+    assert pk is not None and pk.shape == (B, 64, H, W)
+    mine = pk.buf.clone()
+    assert torch.equal(ops.conv3x3_pack_act(got.view(B, 64, H, W).clone()).buf, mine)
