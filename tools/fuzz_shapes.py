@@ -109,5 +109,46 @@ for it in range(8):
     gf, gs = ops.point_heads(x0[:, :Ca].contiguous(), x0[:, Ca:].contiguous() if Ca < 128 else None, layers, (ops.gemm_pack_weight(wl), bl, 2), 3, 4)
     chk("heads", (gf.double() - feat).abs().max().item() < 5e-5 * max(1.0, feat.abs().max().item())
         and (gs.double() - seg).abs().max().item() < 1e-4 * max(1.0, seg.abs().max().item()), (B, N, Ca))
+# round 3: the kernels added in the second half of the round, at ragged sizes
+for it in range(16):                                             # LFA stages on the fp32 MFMA vs the separate-kernel chain
+    d_out, n, B = int(rs.choice([32, 64, 128, 256])), rs.randint(1, 300), rs.randint(1, 4)
+    torch.manual_seed(it)
+    blk = randla.BuildingBlock(d_out).cuda().eval()
+    for mod in blk.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.5); mod.running_var.uniform_(0.5, 2.0); mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.3)
+    xyz = torch.randn(B, n, 3, device="cuda"); feat = torch.randn(B, d_out // 2, n, 1, device="cuda")
+    idx = torch.randint(0, n, (B, n, 16), device="cuda", dtype=torch.int32)
+    with torch.no_grad():
+        settings.USE_FUSED_LFA = False; ref = blk(xyz, feat, idx)
+        settings.USE_FUSED_LFA = True; got = blk(xyz, feat, idx)
+    chk("lfa", (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (d_out, n, B))
+for it in range(24):                                             # one-pass weight + bias gradient, sliced operands
+    B, Cin, Cout, P = rs.randint(1, 6), rs.randint(1, 129), rs.randint(1, 129), 32 * rs.randint(16, 600)
+    if B * P < 16384: P = 32 * (16384 // (32 * B) + 1)
+    xw = torch.randn(B, Cin + 4, P, device="cuda"); gw = torch.randn(B, Cout + 8, P, device="cuda")
+    x, go = xw[:, 4:], gw[:, :Cout]
+    if not ops.wgrad_direct_supported(x, go, bias=True): continue
+    w, b_ = ops.wgrad_direct(x, go, bias=True)
+    rw_ = torch.bmm(go.double(), x.double().transpose(1, 2)).sum(0); rb = go.double().sum((0, 2))
+    chk("wgrad_direct", (w.double() - rw_).norm().item() < 3e-5 * rw_.norm().item() and (b_.double() - rb).abs().max().item() < 1e-4 * max(1.0, rb.abs().max().item()), (B, Cin, Cout, P))
+for it in range(10):                                             # producers that write the packed operand themselves
+    B, H = rs.randint(1, 5), int(rs.choice([8, 16, 32]))
+    C, W = int(rs.choice([64, 128, 256])), 32
+    if (B * H * W) % 256: continue
+    g = torch.randn(B, C, H, W, device="cuda"); ys = [torch.randn(B, C, s_, s_, device="cuda") for s_ in (1, 2, 3, 6)]; bias = torch.randn(C, device="cuda")
+    a = ops.psp_combine(g.clone(), ys, bias); b2 = ops.psp_combine(g.clone(), ys, bias, packed=True)
+    ok = torch.equal(a, b2) and torch.equal(ops.conv3x3_pack_act(b2.clone()).buf, b2._gdm_packed.buf.clone())
+    z = torch.randn(B, 9 * C, H // 2, W // 2, device="cuda"); sc = torch.rand(C, device="cuda") + 0.5; sh = torch.randn(C, device="cuda")
+    a = ops.upconv3x3_gather(z, sc, sh, C, (H, W), 2, 0.25); b2 = ops.upconv3x3_gather(z, sc, sh, C, (H, W), 2, 0.25, packed=True)
+    ok = ok and torch.equal(a, b2) and torch.equal(ops.conv3x3_pack_act(b2.clone()).buf, b2._gdm_packed.buf.clone())
+    chk("packed_producers", ok, (B, C, H, W))
+for it in range(8):                                              # 3x3 convolution, 128 -> 128: half tiles at small batch
+    B, H = rs.randint(1, 6), int(rs.choice([8, 32]))
+    if (B * H * 32) % 128: continue
+    x = torch.randn(B, 128, H, 32, device="cuda"); w = torch.randn(128, 128, 3, 3, device="cuda") / 34
+    got = ops.conv3x3_bf16x3(x, ops.conv3x3_pack_weight(w), 128)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    chk("conv_half_tiles", (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (B, H))
 torch.cuda.synchronize()
 print("fuzz done, mismatches:", bad)
