@@ -449,7 +449,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from geometric_aware_dense_matching_amd import _lib, ops, pyramid, settings, synthetic
+    from geometric_aware_dense_matching_amd import _lib, matching, ops, pyramid, settings, synthetic
     from geometric_aware_dense_matching_amd.config import make_model_cfg
     from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
 
@@ -503,15 +503,16 @@ def main():
             ep = model(d)
             if record:
                 e[2].record()
-            mask, count = ops.seg_mask(ep["seg"])
-            srows = ops.match_pack(ep["rgbd"], prec)
-            mrows = ops.match_pack(ep["mesh"][0], prec)
             if record:
+                mask, count = ops.seg_mask(ep["seg"])
+                srows = ops.match_pack(ep["rgbd"], prec)
+                mrows = ops.match_pack(ep["mesh"][0], prec)
                 e[3].record()
-            bi, bs = ops.match_packed(srows, mrows, B, N, M, prec)
-            if record:
+                bi, bs = ops.match_packed(srows, mrows, B, N, M, prec)
                 e[4].record()
                 stage_ev.append(e)
+            else:
+                mask, count, bi, bs = matching.match_tail(ep, B, N, M, prec)      # the same four launches (forked: mask beside the arg-max)
         out = {k: v for k, v in pyr.items() if torch.is_tensor(v)}
         out.update(best_idx=bi, best_sim=bs, mask=mask, rgbd=ep["rgbd"], seg=ep["seg"])
         return out

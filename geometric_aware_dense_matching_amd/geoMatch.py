@@ -181,6 +181,7 @@ class GeoMatch(nn.Module):
             end_points = {}
         rgb = inputs["rgb"]
         late_join = None
+        mesh_rows = None
         heads = self._fused_heads(rgb)
         # the fused heads read the two halves of the embedding in place: no concat launch
         emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
@@ -201,9 +202,11 @@ class GeoMatch(nn.Module):
                 rgbd_emb = emb(inputs)
                 with ops.fork(rgb.device, 1, start=ev0) as f:
                     mesh_features = self.mesh_features()
+                    # the matching kernel's operand rows of the model descriptors, formed here (off the step's serial tail)
+                    mesh_rows = ops.match_pack(mesh_features, ops.MATCH_BF16X3) if settings.PACK_MESH_ROWS else None
                 late_join = f if heads is not None else None      # the fused heads do not read the mesh: join behind them
                 if late_join is None:
-                    f.join(mesh_features)
+                    f.join(mesh_features, mesh_rows)
             else:
                 with ops.fork(rgb.device, 1) as f:           # reads module buffers / parameters only (never freed mid-step)
                     mesh_features = self.mesh_features()
@@ -217,7 +220,7 @@ class GeoMatch(nn.Module):
             a, b = rgbd_emb if isinstance(rgbd_emb, tuple) else (rgbd_emb, None)
             rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
             if late_join is not None:
-                late_join.join(mesh_features)
+                late_join.join(mesh_features, mesh_rows)
         else:
             rgbd_features = self.feature_encoding_layer(rgbd_emb)
             rgbd_normalized = self.normalize_feature_layer(rgbd_features)
@@ -233,6 +236,8 @@ class GeoMatch(nn.Module):
             end_points["match_loss"] = match_loss
 
         end_points["seg"] = seg_features
+        if mesh_rows is not None:
+            end_points["mesh_rows"] = mesh_rows          # u8 packed rows for ops.match_packed (matching.match_tail reads them)
         end_points["mesh"] = mesh_features
         end_points["rgbd"] = rgbd_features
         return end_points

@@ -29,6 +29,30 @@ def match_frames(end_points, precision="bf16x3", return_sim=False):
     return res
 
 
+def match_tail(end_points, B, N, M, precision=ops.MATCH_BF16X3):
+    """The step's tail on packed rows (evaluator.py:78-93): seg mask, descriptor packs, N x M arg-max -> (mask, count, best_idx, best_sim).
+    With settings.USE_SIDE_STREAMS the mask -- which the arg-max does not read -- is formed on a side stream beside the matching
+    kernel, and the model's descriptor rows are taken from `end_points["mesh_rows"]` when GeoMatch.forward packed them inside its
+    mesh fork (same kernels, same operands: same bits)."""
+    from . import settings
+    seg, rgbd, mesh = end_points["seg"], end_points["rgbd"], end_points["mesh"]
+    forked = settings.USE_SIDE_STREAMS and seg.is_cuda and not torch.is_grad_enabled()
+    srows = ops.match_pack(rgbd, precision)
+    mrows = end_points.get("mesh_rows") if precision == ops.MATCH_BF16X3 else None
+    if mrows is None:
+        mrows = ops.match_pack(mesh[0] if mesh.dim() == 3 else mesh, precision)
+    if forked:
+        with ops.fork(seg.device, 0) as f:
+            f.use(seg)
+            mask, count = ops.seg_mask(seg)
+        bi, bs = ops.match_packed(srows, mrows, B, N, M, precision)
+        f.join(mask, count)
+    else:
+        mask, count = ops.seg_mask(seg)
+        bi, bs = ops.match_packed(srows, mrows, B, N, M, precision)
+    return mask, count, bi, bs
+
+
 def selected(res, b):
     """(obj_pts_idx, max_th) of crop b for the points with seg arg-max == 1, in point order
     (evaluator.py:83-93)."""

@@ -332,10 +332,8 @@ def _bench_step(model, inputs, cld, dpt_xyz, B, overlap=True):
     d = dict(inputs)
     d.update(pyr)
     ep = model(d)
-    mask, count = ops.seg_mask(ep["seg"])
-    srows = ops.match_pack(ep["rgbd"], ops.MATCH_BF16X3)
-    mrows = ops.match_pack(ep["mesh"][0], ops.MATCH_BF16X3)
-    bi, bs = ops.match_packed(srows, mrows, B, N2, M2, ops.MATCH_BF16X3)
+    from geometric_aware_dense_matching_amd import matching
+    mask, count, bi, bs = matching.match_tail(ep, B, N2, M2, ops.MATCH_BF16X3)
     out = {k: v for k, v in pyr.items() if torch.is_tensor(v)}
     out.update(rgbd=ep["rgbd"], seg=ep["seg"], mesh=ep["mesh"], mask=mask, best_idx=bi, best_sim=bs)
     return out
