@@ -295,11 +295,37 @@ def light_extras(torch, dev, args, model, N, M):
         b = synthetic.make_batch(seed=seed, batch=B, n_points=N)
         return {k: torch.from_numpy(b[k]).to(dev) for k in ("rgb", "cld_rgb_nrm", "choose", "dpt_xyz")}
 
+    def best_replay(batch):
+        """(ms per replay, launch form): the single-stream capture of infer.GraphedPipeline, or -- when its outputs equal that capture's bit
+        for bit, before and after its timed replays -- the same pipeline captured with the side-stream forks."""
+        from geometric_aware_dense_matching_amd import settings
+        gp = infer.GraphedPipeline(model, batch, precision=prec, with_pose=False)
+        gp.graph.replay()
+        torch.cuda.synchronize()
+        ref = {k: v.clone() for k, v in gp.static_out.items()}
+        ms, launch = timed(gp.graph.replay, 10, torch), "hipGraph replay"
+        if settings.USE_SIDE_STREAMS or args.no_forked:
+            return ms, launch
+        try:
+            settings.USE_SIDE_STREAMS = True
+            gf = infer.GraphedPipeline(model, batch, precision=prec, with_pose=False)
+            gf.graph.replay()
+            torch.cuda.synchronize()
+            same = all(torch.equal(ref[k], gf.static_out[k]) for k in ref)
+            msf = timed(gf.graph.replay, 10, torch)
+            same = same and all(torch.equal(ref[k], gf.static_out[k]) for k in ref)
+            if same and msf < ms:
+                ms, launch = msf, "hipGraph replay, forked (bit-identical to the single-stream replay)"
+        except Exception:                                       # noqa: BLE001 -- the forked form is an extra candidate only
+            torch.cuda.synchronize()
+        finally:
+            settings.USE_SIDE_STREAMS = False
+        return ms, launch
+
     def b32():
         # ---- batch 32, hipGraph replay (pyramid + forward + matching)
-        gp = infer.GraphedPipeline(model, dev_batch(300, 32), precision=prec, with_pose=False)
-        ms = timed(gp.graph.replay, 10, torch)
-        out["b32"] = {"crops_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": "hipGraph replay"}
+        ms, launch = best_replay(dev_batch(300, 32))
+        out["b32"] = {"crops_per_s": round(32 / ms * 1e3, 1), "ms_per_step": round(ms, 3), "launch": launch}
 
     def mesh_cached():
         # ---- the deployment form: the object's mesh descriptors depend on the weights only, so a server computes them once per object
@@ -308,10 +334,9 @@ def light_extras(torch, dev, args, model, N, M):
             return
         model.cache_mesh_in_eval = True
         try:
-            gp = infer.GraphedPipeline(model, dev_batch(302, args.batch), precision=prec, with_pose=False)
-            ms = timed(gp.graph.replay, 10, torch)
+            ms, launch = best_replay(dev_batch(302, args.batch))
             out["mesh_cached"] = {"crops_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "batch": args.batch,
-                                  "launch": "hipGraph replay", "what": "mesh branch computed once per object instead of once per step"}
+                                  "launch": launch, "what": "mesh branch computed once per object instead of once per step"}
         finally:
             model.cache_mesh_in_eval = False
             model._mesh_cache = None
