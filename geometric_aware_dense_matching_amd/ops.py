@@ -17,6 +17,7 @@ Operator <-> reference map (file:line under /root/reference):
   ballquery / furthestsampling   lib/pointops/functions/pointops.py:205-219, 40-50
 """
 import ctypes
+import os
 
 import torch
 
@@ -40,7 +41,12 @@ def side_stream(device, which=0):
     key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _side_streams.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        # GDM_SIDE_PRIORITY="k:p,..." (development): HIP stream priority p (-1 = high) for side stream k
+        prio = 0
+        for item in os.environ.get("GDM_SIDE_PRIORITY", "").split(","):
+            if ":" in item and int(item.split(":")[0]) == which:
+                prio = int(item.split(":")[1])
+        st = torch.cuda.Stream(device=device, priority=prio)
         _side_streams[key] = st
     return st
 
