@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time the eager step loop only (no hipGraph capture)")
     ap.add_argument("--graph-only", action="store_true", help="headline = the hipGraph replays even where the eager loop is faster")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-32 / mesh-cached / per-kernel roofline legs (and the heavy ones)")
+    ap.add_argument("--strict", action="store_true", help="exit 3 (after printing the line) if the hipGraph replay fails its check against the eager step")
     ap.add_argument("--no-forked", action="store_true", help="do not offer the side-stream (forked) hipGraph form to the timing")
     ap.add_argument("--no-heavy-extras", action="store_true", help="skip the legs that run after the JSON line (exact-f32, DGCNN, training step)")
     return ap.parse_args()
@@ -567,7 +568,7 @@ def main():
         if not args.eager:
             # one capture of the whole step on the resident inputs (after the eager warm-up above); every timed step below is one
             # replay = the same kernels, one host call.  The replay is CHECKED against the eager step, and the result recorded
-            # (graph_check); a replay outside north_star's tolerance is not timed -- the eager loop is, and the run exits non-zero
+            # (graph_check); a replay outside north_star's tolerance is not timed -- the eager loop is, and the line says so (--strict: exit 3 after printing)
             ref = {k: v.clone() for k, v in step().items()}
             torch.cuda.synchronize()
             ref2 = {k: v.clone() for k, v in step().items()}
@@ -721,7 +722,7 @@ def main():
     def on_term(signum, frame):
         line["terminated"] = "signal %d after %.0f s" % (signum, time.perf_counter() - t_start)
         emit()
-        os._exit(4 if (check is None or check.get("ok")) else 3)
+        os._exit(4)
     if rank == 0:
         signal.signal(signal.SIGTERM, on_term)
 
@@ -805,8 +806,10 @@ def main():
             pass
     if world > 1:
         dist.destroy_process_group()
-    if check is not None and not check.get("ok"):
-        sys.exit(3)                                            # the line is out; the exit code says the replay was outside tolerance
+    if args.strict and check is not None and not check.get("ok"):
+        sys.exit(3)                                            # --strict: the exit code also says the replay was outside tolerance
+    # without --strict a replay outside tolerance costs the replay forms only: the line is out, timed on the eager loop, with
+    # graph_check.ok = false in it -- a measurement the driver can read, not a lost run
 
 
 if __name__ == "__main__":
