@@ -203,7 +203,7 @@ def kernel_rooflines(torch, dev, B, N):
     out.append({"kernel": "conv_mfma16_kernel 3x3 512->512 @32x32 (trunk layer4)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
-                "traffic": traffic("conv_mfma16_kernel<0, false, 9, false, 8, 8>"),
+                "traffic": traffic("conv_mfma16_kernel<0, false, 9, false, 8, 8"),
                 "mfma_probe_tflops": None if not probe else round(probe, 1), "frac_of_probe": vs_probe(3 * fl / ms / 1e9),
                 "mfma_probe_chain3_tflops": None if not probe_chain3 else round(probe_chain3, 1),
                 "work": "2*9*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * H * W)})
@@ -255,7 +255,7 @@ def kernel_rooflines(torch, dev, B, N):
     out.append({"kernel": "conv_mfma16_kernel 1x1 1024->2304 @32x32 (tap GEMM of up_1)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
-                "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 8>"),
+                "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 8"),
                 "mfma_probe_tflops": None if not probe else round(probe, 1), "frac_of_probe": vs_probe(3 * fl / ms / 1e9),
                 "work": "2*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * 32 * 32)})
     # (5) the last image stage at the sampled pixels (up_3 + final at `choose`): replaces a 64 -> 64 3x3 convolution and a 1x1 + log-softmax
@@ -272,7 +272,7 @@ def kernel_rooflines(torch, dev, B, N):
     by = 4.0 * B * 64 * (128 * 128 + N)
     out.append({"kernel": "upconv_final_points_kernel: up_3 + final at the %d sampled pixels of 256^2" % N, "bound": "hbm", "unit": "GB/s",
                 "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "avg_ms": round(ms, 4), "traffic": None,
+                "avg_ms": round(ms, 4), "traffic": traffic("upconv_final_points_kernel"),
                 "work": "reads the 64-channel 128^2 source map once, writes 64 x N floats per crop; latency-bound at this size (1024 workgroups of 10 barriers)"})
     return out
 

@@ -17,16 +17,17 @@ B, N, M = 16, 2048, 8192
 KERNELS = collections.OrderedDict([
     ("match_pipe_sim_kernel", ("N x 8192 descriptor kernel, materialised", 4.0 * 128 * (B * N + M) + 4.0 * B * N * M)),
     ("match_pipe_kernel", ("N x 8192 descriptor kernel, fused arg-max", 4.0 * 128 * (B * N + M) + 8.0 * B * N)),
-    ("conv_mfma16_kernel<0, false, 9, false, 8, 8>", ("3x3 512->512 @32x32 (packed operands in, fp32 NCHW out)",
+    ("conv_mfma16_kernel<0, false, 9, false, 8, 8", ("3x3 512->512 @32x32 (packed operands in, fp32 NCHW out)",
                                                        B * 34 * 34 * 4 * 512.0 + 9 * 4 * 512 * 512.0 + 4.0 * B * 512 * 1024)),
-    ("conv_mfma16_kernel<0, false, 1, false, 8, 8>", ("1x1 1024->2304 @32x32 (tap GEMM of up_1)",
+    ("conv_mfma16_kernel<0, false, 1, false, 8, 8", ("1x1 1024->2304 @32x32 (tap GEMM of up_1)",
                                                        B * 34 * 34 * 8 * 512.0 + 8 * 2304 * 512.0 + 4.0 * B * 2304 * 1024)),
     ("knn_wave_kernel", ("K = 16 searches of the pyramid (unorganised supports)", None)),
     ("knn_kernel<1>", ("K = 1 searches of the pyramid", None)),
     ("knn_grid_kernel", ("K = 16 searches against organised supports (window search)", None)),
     ("gather_max_", ("gather + max over K, C=64, 16384 px -> 512 points", 4.0 * B * (64 * 16384 + 16 * 512 + 64 * 512))),
     ("stem_kernel", ("conv7x7/2 + BN + ReLU + max-pool, 256^2 -> 64 x 64^2", 4.0 * B * 3 * 65536 + 49152 + 4.0 * B * 64 * 4096 * 2)),
-    ("lfa_stage_kernel<32>", ("LFA stage level 0 (n = 2048, D = 32)", None)),
+    ("lfa_stage_mfma_kernel<32", ("LFA stage level 0 (n = 2048, D = 32), MFMA form", None)),
+    ("upconv_final_points_kernel", ("up_3 + final at the 2048 sampled pixels of 256^2", 4.0 * B * 64 * (128 * 128 + N))),
 ])
 
 
@@ -57,6 +58,11 @@ def launch():
     w = {k: torch.randn(*s, device=dev) * 0.1 for k, s in dict(w1t=(10, D // 2), wf=(D, D), wm=(D, D // 2)).items()}
     s1 = torch.ones(D // 2, device=dev)
     f0 = torch.randn(B, D // 2, N, device=dev)
+    xs = torch.randn(B, 128 * 128, 64, device=dev)
+    ch = torch.randint(0, 256 * 256, (B, N), device=dev, dtype=torch.int32)
+    wk = ops.upconv_fused64_pack_weight(torch.randn(64, 64, 3, 3, device=dev) * 0.05)
+    wf = ops.pack_rows64(torch.randn(64, 64, device=dev) / 8)
+    bf = torch.zeros(64, device=dev)
     for _ in range(5):
         ops.match_packed(srows, mrows, B, N, M, 0, return_sim=True, sim_out=sim)
         ops.match_packed(srows, mrows, B, N, M, 0)
@@ -66,6 +72,7 @@ def launch():
         ops.gather_max(feat, idx)
         ops.stem(rgb, swp, sc, sh)
         ops.lfa_stage(pyr["cld_xyz0"], pyr["cld_nei_idx0"], f0, w["w1t"], s1, s1, None, None, None, w["wf"], w["wm"], s1, s1)
+        ops.upconv_final_points(xs, (128, 128), ch, wk, sc, sh, 2, 0.25, wf, bf, (256, 256))
     torch.cuda.synchronize()
     print("ok")
 
