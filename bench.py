@@ -526,7 +526,7 @@ def main():
                 e[1].record()
             d = dict(inputs)
             d.update(pyr)
-            ep = model(d)
+            ep = model(d) if record else model(d, defer_seg=True)     # defer_seg only acts with the side-stream forks (match_tail joins)
             if record:
                 e[2].record()
             if record:

@@ -93,6 +93,7 @@ SIGNATURES = {
     "gdm_conv64_gather_add_act_mfma_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _i, _f, _i, _i, _vp, _vp]),
     "gdm_conv64_gather_add_act_mfma2_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _i, _f, _i, _i, _vp, _vp, _i, _vp]),
     "gdm_point_heads_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "gdm_point_heads2_hip": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gdm_upconv_final_points_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_conv3x3_act_bytes": (_sz, [_i, _i, _i, _i]),
     "gdm_conv3x3_weight_bytes": (_sz, [_i, _i]),

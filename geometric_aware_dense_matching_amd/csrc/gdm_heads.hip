@@ -40,9 +40,12 @@ struct HeadArgs {
     const unsigned char* w_last;
     const float* shift_last;              // bias of the last layer (NULL = 0)
     int c_last;
-    float* out_feat;                      // f32[B, 128, N]
-    float* out_last;                      // f32[B, c_last, N]
+    float* out_feat;                      // f32[B, 128, N] (NULL with feat_layer < 0)
+    float* out_last;                      // f32[B, c_last, N] (unused with c_last == 0: the chain then ends with its hidden layers)
     int Ca, N;
+    const float* ra;                      // the tensor added at res_layer, as (first rCa channels, the rest): the input itself by default
+    const float* rb;
+    int rCa;
 };
 
 __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
@@ -55,6 +58,13 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
 
     auto x0_at = [&](int c, int p) -> float {                     // input channel c of point n0 + p (0 beyond N); no control flow
         const float* src = c < Ca ? A.a + ((long)b * Ca + c) * N : A.b + ((long)b * Cb + (c - Ca)) * N;
+        const float v = src[min(n0 + p, N - 1)];
+        return n0 + p < N ? v : 0.f;
+    };
+
+    auto r_at = [&](int c, int p) -> float {                      // residual source channel c of point n0 + p
+        const int rCa = A.rCa;
+        const float* src = c < rCa ? A.ra + ((long)b * rCa + c) * N : A.rb + ((long)b * (HD_C - rCa) + (c - rCa)) * N;
         const float v = src[min(n0 + p, N - 1)];
         return n0 + p < N ? v : 0.f;
     };
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
         // the next layer's weights go out now: in flight during this epilogue and the barrier
         const bool last_next = l + 1 == A.nlayer;
         if (!last_next) weights_load(A.w[l + 1], 2);
-        else if (wave == 0) weights_load(A.w_last, 1);
+        else if (wave == 0 && A.c_last > 0) weights_load(A.w_last, 1);
         const float* sc = A.scale[l];
         const float* sh = A.shift[l];
         const int act = A.act[l];
@@ -142,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
                 for (int r = 0; r < 4; ++r) {
                     float o = acc[cb][pb][r] * s4[r] + h4[r];
                     if (act == 1) o = fmaxf(o, 0.f);
-                    if (res) o = x0_at(c0 + r, p) + o;             // rgbd_emb + rgbd_normalized (geoMatch.py:178)
+                    if (res) o = r_at(c0 + r, p) + o;              // rgbd_emb + rgbd_normalized (geoMatch.py:178)
                     v[r] = o;
                 }
-                if (feat && n0 + p < N) {
+                if (feat && A.out_feat && n0 + p < N) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) A.out_feat[((long)b * HD_C + c0 + r) * N + n0 + p] = v[r];
                 }
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
     }
     __syncthreads();
     // ---- the last layer: c_last <= 16 output channels, one 16-row block on wave 0 ----
-    if (wave == 0) {
+    if (wave == 0 && A.c_last > 0) {
         mma(rows + (A.nlayer & 1) * HD_BUF, 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -180,23 +190,45 @@ __global__ __launch_bounds__(256, 2) void point_heads_kernel(HeadArgs A)
 } // namespace
 
 /* see include/gdm.h */
+extern "C" int gdm_point_heads2_hip(const float* a, const float* b, int Ca, const float* ra, const float* rb, int rCa, int B, int N, int nlayer,
+                                    const void* const* w, const float* const* scale, const float* const* shift, const int* act, int feat_layer,
+                                    int res_layer, const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last,
+                                    void* stream);
+
 extern "C" int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, int nlayer, const void* const* w,
                                    const float* const* scale, const float* const* shift, const int* act, int feat_layer, int res_layer,
                                    const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last, void* stream)
 {
-    GDM_CHECK_ARG(a && w && scale && shift && act && w_last && out_feat && out_last, "gdm_point_heads_hip: NULL pointer");
-    GDM_CHECK_ARG(Ca >= 8 && Ca <= HD_C && Ca % 8 == 0 && (b || Ca == HD_C), "gdm_point_heads_hip: Ca=%d (a multiple of 8, with b unless 128)", Ca);
-    GDM_CHECK_ARG(B >= 1 && B <= 65535 && N >= 1 && nlayer >= 1 && nlayer <= HD_MAXL && c_last >= 1 && c_last <= 16,
-                  "gdm_point_heads_hip: B=%d N=%d nlayer=%d c_last=%d", B, N, nlayer, c_last);
-    GDM_CHECK_ARG(feat_layer >= -1 && feat_layer < nlayer && res_layer >= -1 && res_layer < nlayer, "gdm_point_heads_hip: bad layer index");
+    GDM_CHECK_ARG(w_last && out_feat && out_last && c_last >= 1, "gdm_point_heads_hip: NULL pointer / c_last=%d", c_last);
+    return gdm_point_heads2_hip(a, b, Ca, a, b, Ca, B, N, nlayer, w, scale, shift, act, feat_layer, res_layer, w_last, shift_last, c_last,
+                                out_feat, out_last, stream);
+}
+
+/* see include/gdm.h */
+extern "C" int gdm_point_heads2_hip(const float* a, const float* b, int Ca, const float* ra, const float* rb, int rCa, int B, int N, int nlayer,
+                                    const void* const* w, const float* const* scale, const float* const* shift, const int* act, int feat_layer,
+                                    int res_layer, const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last,
+                                    void* stream)
+{
+    GDM_CHECK_ARG(a && w && scale && shift && act, "gdm_point_heads2_hip: NULL pointer");
+    GDM_CHECK_ARG(Ca >= 8 && Ca <= HD_C && Ca % 8 == 0 && (b || Ca == HD_C), "gdm_point_heads2_hip: Ca=%d (a multiple of 8, with b unless 128)", Ca);
+    GDM_CHECK_ARG(B >= 1 && B <= 65535 && N >= 1 && nlayer >= 1 && nlayer <= HD_MAXL && c_last >= 0 && c_last <= 16,
+                  "gdm_point_heads2_hip: B=%d N=%d nlayer=%d c_last=%d", B, N, nlayer, c_last);
+    GDM_CHECK_ARG(c_last == 0 || (w_last && out_last), "gdm_point_heads2_hip: last layer without weights / output");
+    GDM_CHECK_ARG(feat_layer >= -1 && feat_layer < nlayer && res_layer >= -1 && res_layer < nlayer, "gdm_point_heads2_hip: bad layer index");
+    GDM_CHECK_ARG(feat_layer < 0 || out_feat, "gdm_point_heads2_hip: feat_layer without out_feat");
+    if (!ra) { ra = a; rb = b; rCa = Ca; }                         // the residual source defaults to the input
+    GDM_CHECK_ARG(res_layer < 0 || (rCa >= 8 && rCa <= HD_C && rCa % 8 == 0 && (rb || rCa == HD_C)),
+                  "gdm_point_heads2_hip: residual source rCa=%d (a multiple of 8, with rb unless 128)", rCa);
     HeadArgs A;
     A.a = a; A.b = b; A.Ca = Ca; A.N = N; A.nlayer = nlayer; A.feat_layer = feat_layer; A.res_layer = res_layer;
+    A.ra = ra; A.rb = rb; A.rCa = rCa;
     for (int l = 0; l < HD_MAXL; ++l) {
         A.w[l] = l < nlayer ? (const unsigned char*)w[l] : nullptr;
         A.scale[l] = l < nlayer ? scale[l] : nullptr;
         A.shift[l] = l < nlayer ? shift[l] : nullptr;
         A.act[l] = l < nlayer ? act[l] : 0;
-        GDM_CHECK_ARG(l >= nlayer || (w[l] && act[l] >= 0 && act[l] <= 1), "gdm_point_heads_hip: layer %d: NULL weights or act=%d", l, l < nlayer ? act[l] : 0);
+        GDM_CHECK_ARG(l >= nlayer || (w[l] && act[l] >= 0 && act[l] <= 1), "gdm_point_heads2_hip: layer %d: NULL weights or act=%d", l, l < nlayer ? act[l] : 0);
     }
     A.w_last = (const unsigned char*)w_last; A.shift_last = shift_last; A.c_last = c_last; A.out_feat = out_feat; A.out_last = out_last;
     static bool attr = false;

@@ -176,7 +176,10 @@ class GeoMatch(nn.Module):
         self.__dict__["_gdm_heads"] = (key, value)
         return value
 
-    def forward(self, inputs, end_points=None):
+    def forward(self, inputs, end_points=None, defer_seg=False):
+        """defer_seg (inference with settings.USE_SIDE_STREAMS and the fused heads): the normalise / segmentation layers are left
+        running on side stream 0 and NOT joined -- `end_points["_seg_fork"]` holds the fork, which the caller joins after it has
+        launched what only needs the features (matching.match_tail does: the N x M arg-max then runs beside those five layers)."""
         if not end_points:
             end_points = {}
         rgb = inputs["rgb"]
@@ -218,7 +221,16 @@ class GeoMatch(nn.Module):
         if heads is not None:
             # feature_encoding_layer, normalize_feature_layer, the residual add and seg_layer: nine per-point 1x1 convolutions, one launch
             a, b = rgbd_emb if isinstance(rgbd_emb, tuple) else (rgbd_emb, None)
-            rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
+            if defer_seg and settings.USE_SIDE_STREAMS and settings.SPLIT_HEADS and len(heads[0]) == 8 and not self.training:
+                # two launches: the four feature layers here; normalise + residual + the segmentation layers on side stream 0, joined
+                # by the caller -- same layers, same operands (the fifth layer's operand rows are split from the same fp32 values)
+                rgbd_features, _ = ops.point_heads(a, b, heads[0][:4], None, feat_layer=3, res_layer=-1)
+                with ops.fork(rgb.device, 0) as sf:
+                    sf.use(rgbd_features, a, b)
+                    _, seg_features = ops.point_heads(rgbd_features, None, heads[0][4:], heads[1], feat_layer=-1, res_layer=0, residual=(a, b))
+                end_points["_seg_fork"] = sf
+            else:
+                rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
             if late_join is not None:
                 late_join.join(mesh_features, mesh_rows)
         else:

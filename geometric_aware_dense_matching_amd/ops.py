@@ -1130,10 +1130,11 @@ def conv1x1_gather_add_act(x, wt, t, idx, scale, shift, act=ACT_NONE, slope=0.0,
     return y
 
 
-def point_heads(a, b, layers, last, feat_layer, res_layer):
+def point_heads(a, b, layers, last, feat_layer, res_layer, residual=None):
     """The per-point 1x1-convolution chain of GeoMatch.forward in one launch (inference).  a f32[B,Ca,N] (+ b f32[B,128-Ca,N] or None);
     layers = [(wpk, scale|None, shift|None, act)] of 128 -> 128 layers (wpk from gemm_pack_weight, act ACT_NONE / ACT_RELU);
-    last = (wpk, bias|None, c_last).  -> (out_feat f32[B,128,N] = affine output of layer feat_layer, out_last f32[B,c_last,N])."""
+    last = (wpk, bias|None, c_last) or None (the chain ends with its hidden layers).  residual = (ra, rb|None): the tensor added at
+    res_layer (default: the input).  -> (out_feat f32[B,128,N] = output of layer feat_layer or None, out_last f32[B,c_last,N] or None)."""
     import ctypes
     a = _dev(a, torch.float32, "a")
     B, Ca, N = a.shape
@@ -1152,12 +1153,22 @@ def point_heads(a, b, layers, last, feat_layer, res_layer):
     for l in layers:
         if l[3] not in (ACT_NONE, ACT_RELU):
             raise ValueError("point_heads: activations are none / ReLU")
-    wl, bl, c_last = last
-    out_feat = torch.empty((B, 128, N), dtype=torch.float32, device=a.device)
-    out_last = torch.empty((B, int(c_last), N), dtype=torch.float32, device=a.device)
-    check(_lib.lib().gdm_point_heads_hip(a.data_ptr(), b.data_ptr() if b is not None else None, Ca, B, N, n, w_arr, sc_arr, sh_arr, act_arr,
-                                         int(feat_layer), int(res_layer), wl.data_ptr(), bl.data_ptr() if bl is not None else None,
-                                         int(c_last), out_feat.data_ptr(), out_last.data_ptr(), _stream()), "gdm_point_heads_hip")
+    wl, bl, c_last = last if last is not None else (None, None, 0)
+    out_feat = torch.empty((B, 128, N), dtype=torch.float32, device=a.device) if feat_layer >= 0 else None
+    out_last = torch.empty((B, int(c_last), N), dtype=torch.float32, device=a.device) if c_last else None
+    ra, rb = (None, None)
+    if residual is not None:
+        ra = _dev(residual[0], torch.float32, "residual")
+        rb = _dev(residual[1], torch.float32, "residual") if residual[1] is not None else None
+        if ra.shape[0] != B or ra.shape[2] != N or ra.shape[1] + (rb.shape[1] if rb is not None else 0) != 128:
+            raise ValueError("point_heads: the residual source must make 128 channels of the same points")
+    check(_lib.lib().gdm_point_heads2_hip(a.data_ptr(), b.data_ptr() if b is not None else None, Ca,
+                                          ra.data_ptr() if ra is not None else None, rb.data_ptr() if rb is not None else None,
+                                          ra.shape[1] if ra is not None else 0, B, N, n, w_arr, sc_arr, sh_arr, act_arr,
+                                          int(feat_layer), int(res_layer), wl.data_ptr() if wl is not None else None,
+                                          bl.data_ptr() if bl is not None else None, int(c_last),
+                                          out_feat.data_ptr() if out_feat is not None else None,
+                                          out_last.data_ptr() if out_last is not None else None, _stream()), "gdm_point_heads2_hip")
     return out_feat, out_last
 
 

@@ -71,6 +71,7 @@ USE_TWO_STREAM_PIPELINE = _flag("GDM_TWO_STREAM_PIPELINE")     # with USE_SIDE_S
 MESH_FORK_LATE = os.environ.get("GDM_MESH_FORK_LATE", "1") != "0"       # with USE_SIDE_STREAMS: the mesh fork is enqueued behind the embedding
 MESH_ON_POINT_STREAM = os.environ.get("GDM_MESH_ON_POINT_STREAM", "0") == "1"   # development: the mesh branch at the head of the point stream
 PACK_MESH_ROWS = os.environ.get("GDM_PACK_MESH_ROWS", "1") != "0"         # with USE_SIDE_STREAMS: the model descriptors' matching rows are packed inside the mesh fork
+SPLIT_HEADS = os.environ.get("GDM_SPLIT_HEADS", "0") == "1"               # development: with USE_SIDE_STREAMS and forward(defer_seg=True) the heads run as two launches (measured: no gain, the arg-max kernel fills the chip)
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))

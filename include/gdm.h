@@ -468,6 +468,14 @@ int gdm_bn_bwd_apply_hip(const float* x, const float* grad_out, const double* su
 int gdm_point_heads_hip(const float* a, const float* b, int Ca, int B, int N, int nlayer, const void* const* w,
                         const float* const* scale, const float* const* shift, const int* act, int feat_layer, int res_layer,
                         const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last, void* stream);
+/* The same chain in pieces: the tensor added at res_layer comes from (ra, rb, rCa) instead of the input (NULL ra = the input), c_last = 0
+ * ends the chain with its hidden layers (w_last / out_last unused), out_feat may be NULL with feat_layer < 0.  GeoMatch.forward launches
+ * the four feature layers first and the normalise / segmentation layers second, so that the matching kernel -- which reads the features
+ * only -- runs beside the second piece. */
+int gdm_point_heads2_hip(const float* a, const float* b, int Ca, const float* ra, const float* rb, int rCa, int B, int N, int nlayer,
+                         const void* const* w, const float* const* scale, const float* const* shift, const int* act, int feat_layer,
+                         int res_layer, const void* w_last, const float* shift_last, int c_last, float* out_feat, float* out_last,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * One per-point (1x1) layer in a single launch (inference): concat-free, BatchNorm / bias / activation / residual branch folded in.

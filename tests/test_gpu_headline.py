@@ -331,7 +331,7 @@ def _bench_step(model, inputs, cld, dpt_xyz, B, overlap=True):
     pyr = pyramid.build_pyramid(cld, dpt_xyz, overlap=overlap)
     d = dict(inputs)
     d.update(pyr)
-    ep = model(d)
+    ep = model(d, defer_seg=True)
     from geometric_aware_dense_matching_amd import matching
     mask, count, bi, bs = matching.match_tail(ep, B, N2, M2, ops.MATCH_BF16X3)
     out = {k: v for k, v in pyr.items() if torch.is_tensor(v)}

@@ -850,3 +850,23 @@ def test_conv64_fusion_kernel_packed_output(ops, B, H, W, n, act):
     assert pk is not None and pk.shape == (B, 64, H, W)
     mine = pk.buf.clone()
     assert torch.equal(ops.conv3x3_pack_act(got.view(B, 64, H, W).clone()).buf, mine)
+
+
+def test_point_heads_in_two_launches_equals_one(ops):
+    """The heads chain as GeoMatch.forward(defer_seg=True) launches it -- four feature layers, then normalise + residual + segmentation
+    layers with the embedding as the residual source -- == the one-launch chain, bit for bit."""
+    rs = np.random.RandomState(7)
+    B, N = 3, 300
+    x0 = torch.from_numpy(rs.randn(B, 128, N).astype(np.float32)).cuda()
+    a, b = x0[:, :64].contiguous(), x0[:, 64:].contiguous()
+    layers = [(ops.gemm_pack_weight(torch.from_numpy((rs.randn(128, 128) / 11).astype(np.float32)).cuda()),
+               None if l == 3 else torch.from_numpy((rs.rand(128) + 0.5).astype(np.float32)).cuda(),
+               None if l == 3 else torch.from_numpy((rs.randn(128) * 0.3).astype(np.float32)).cuda(), 0 if l == 3 else 1) for l in range(8)]
+    last = (ops.gemm_pack_weight(torch.from_numpy((rs.randn(2, 128) / 11).astype(np.float32)).cuda()),
+            torch.from_numpy(rs.randn(2).astype(np.float32)).cuda(), 2)
+    feat1, seg1 = ops.point_heads(a, b, layers, last, 3, 4)
+    feat2, none = ops.point_heads(a, b, layers[:4], None, 3, -1)
+    assert none is None
+    none2, seg2 = ops.point_heads(feat2, None, layers[4:], last, -1, 0, residual=(a, b))
+    assert none2 is None
+    assert torch.equal(feat1, feat2) and torch.equal(seg1, seg2)
