@@ -788,8 +788,11 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     // points had been missing from the LDS tile (tools/diag_fork_race.py: 20-90 differing arrays in 40 rounds of 5 replays; 0 with
     // knn_kernel<1>, 0 with a synchronize between replays).  That was with the K = 1 launch directly behind the pyramid's first copy
     // kernel; since the pyramid is built in two parts (the K = 1 launch now follows knn_wave_kernel and the second copy) the same
-    // stress shows 0 with this kernel too, in all of its variants (no unroll / scalar arithmetic / 16-byte LDS reads).  The cause was
-    // not found in the round, so the kernel stays opt-in.
+    // stress shows 0 with this kernel too.  Back in the old order (GDM_PYR_SINGLE=1) the variants separate: -DGDM_K1P_SCALAR (same
+    // kernel, the two queries' distances through dist2_ref) 0 differing arrays in 40 rounds, the packed forms (as is / no unroll /
+    // 16-byte LDS reads) 147-166 -- so it is the packed distance arithmetic of THIS kernel (v_pk_add_f32 with op_sel broadcast + neg
+    // modifiers, destination = a source pair) under concurrent execution, not its structure; ordered runs are bit-exact.  Not
+    // understood further in the round: the kernel stays opt-in, and nothing else in the step uses that instruction form on its results.
     static int pair_env = -1;
     if (pair_env < 0) {
         const char* e = getenv("GDM_KNN1_PAIR");
