@@ -67,17 +67,16 @@ struct KnnTable {
     int B;
 };
 
-typedef __attribute__((ext_vector_type(2))) float knn_v2f;
 __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float px, float py, float pz)
 {
-    // nanoflann.hpp:343-346 for dim == 3: result = ((0 + d0*d0) + d1*d1) + d2*d2, diff = query - point.
-    // The x and y components go through the packed fp32 ALU together (v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per
-    // instruction, each rounded like the scalar one; the file is compiled with -ffp-contract=off, so no mul is fused into an add):
-    // 6 vector instructions per pair instead of 8, same bits.
-    const knn_v2f e = knn_v2f{qx, qy} - knn_v2f{px, py};
-    const knn_v2f m = e * e;
+    // nanoflann.hpp:343-346 for dim == 3: result = ((0 + d0*d0) + d1*d1) + d2*d2, diff = query - point.  Scalar, explicitly rounded
+    // operations (a packed x / y form -- v_pk_add_f32 / v_pk_mul_f32, same bits -- was measured: no faster, and see the note at
+    // knn1_pair_kernel's launch about packed arithmetic under concurrent replays)
+    const float d0 = __fsub_rn(qx, px);
+    const float d1 = __fsub_rn(qy, py);
     const float d2 = __fsub_rn(qz, pz);
-    float r = __fadd_rn(m.x, m.y);
+    float r = __fmul_rn(d0, d0);
+    r = __fadd_rn(r, __fmul_rn(d1, d1));
     r = __fadd_rn(r, __fmul_rn(d2, d2));
     return r;
 }

@@ -93,8 +93,9 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
             dense[0].add_(0.0)                                   #   ... with one more kernel in between
     outs = [None] * len(jobs)
     pyr = {}
+    hold = _keep if _keep is not None else []          # both workspaces live until the function returns
     if first:
-        for i, o in zip(first, ops.knn_jobs([jobs[i] for i in first], B, keep_workspace=_keep)):
+        for i, o in zip(first, ops.knn_jobs([jobs[i] for i in first], B, keep_workspace=hold)):
             outs[i] = o
         pyr = dict((names[i], outs[i]) for i in first)
         subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])     # pooling indices: prefix rows, dense
@@ -102,7 +103,7 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(cld.device))
             pyr[READY_CLOUD] = ev
-    for i, o in zip(rest, ops.knn_jobs([jobs[i] for i in rest], B, keep_workspace=_keep)):
+    for i, o in zip(rest, ops.knn_jobs([jobs[i] for i in rest], B, keep_workspace=hold)):
         outs[i] = o
     pyr.update((names[i], outs[i]) for i in rest)
     if not first:

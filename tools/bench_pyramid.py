@@ -10,7 +10,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 batch = synthetic.make_batch(seed=100, batch=B, n_points=N)
 cld = pyramid.cloud_from_inputs(torch.from_numpy(batch["cld_rgb_nrm"]).cuda())
 xyz = torch.from_numpy(batch["dpt_xyz"]).cuda()
-for _ in range(3):
+for _ in range(200):                       # ~60 ms: a chip coming out of idle runs its first tens of milliseconds several times slower
     pyramid.build_pyramid(cld, xyz)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
