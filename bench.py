@@ -138,9 +138,16 @@ def timed_launches(fn, n, torch):
             with torch.cuda.graph(g):
                 for _ in range(n):
                     fn()
-        g.replay()
-        torch.cuda.synchronize()
+        # warm-up: the rooflines run behind the CPU-baseline leg (the GPU idle for ~20 s), and a chip coming out of idle runs its first
+        # tens of milliseconds several times slower (tools/bench_pyramid.py: 2.2 vs 0.26 ms per pyramid): replay for >= 60 ms first
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        for _ in range(min(200, int(60.0 / max(a.elapsed_time(b), 0.05)) + 1)):
+            g.replay()
+        torch.cuda.synchronize()
         a.record()
         g.replay()
         b.record()
