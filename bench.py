@@ -626,6 +626,13 @@ def main():
         # on the same inputs: the check above is what makes them interchangeable) and the line says which it was
         dt_graph = dt_forked = None
         # (every rank passes every barrier, whether or not it has the form to time: a rank whose capture failed must not hang the others)
+        # Each form gets a few untimed steps of its own first: the captures above leave the GPU idle for hundreds of milliseconds, and a
+        # chip coming out of idle runs its first tens of milliseconds slower -- the form timed first must not pay for that.
+        nwarm = max(3, min(args.warmup, 10))
+        if graph is not None:
+            for _ in range(nwarm):
+                graph.replay()
+        sync_all()
         t0 = time.perf_counter()
         if graph is not None:
             for _ in range(args.steps):
@@ -639,6 +646,10 @@ def main():
             check["after_timed_replays_bit_identical"] = bool(after.get("bit_identical"))
             if not after.get("ok"):
                 dt_graph = None
+        if graph_forked is not None:
+            for _ in range(nwarm):
+                graph_forked.replay()
+        sync_all()
         t0 = time.perf_counter()
         if graph_forked is not None:
             for _ in range(args.steps):
@@ -653,6 +664,9 @@ def main():
                 dt_forked = None                                   # a form whose timed replays drifted is not the headline
         if not args.eager:
             del ref, ref2
+        for _ in range(nwarm):
+            step()
+        sync_all()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()

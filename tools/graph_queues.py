@@ -1,6 +1,7 @@
 """One forked hipGraph replay of bench.py from a rocprofv3 kernel trace, with the hardware queue of every kernel: the graph executor
 spreads a graph over very few queues, and which branch shares a queue with which decides what waits.  Development aid.
-usage: graph_queues.py <kernel_trace.csv> [steps back from the last marker, default 18 = a forked replay of `bench.py --steps 10`]"""
+usage: graph_queues.py <kernel_trace.csv> [steps back from the last marker, default 18 = a forked replay of `bench.py --steps 10
+--warmup 3`; 31 = a single-stream replay of the same run (see tools/step_sequence.py for the layout)]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

@@ -1,6 +1,7 @@
 """Ordered kernel list of ONE step from a rocprofv3 kernel trace: start offset, duration, idle gap before it.  Development aid.
 usage: step_sequence.py <kernel_trace.csv> [marker substring, default knn_grid_ranges] [steps back from the last one, default 0]
-(bench.py --steps K: the K forked replays are steps K+5 .. 2K+4 back from the end, the K single-stream replays 2K+5 .. 3K+4 back)"""
+(bench.py --steps K --warmup W, w = max(3, min(W, 10)) untimed steps in front of each form: from the end 5 instrumented eager steps,
+K timed + w eager, K timed + w forked replays (K+w+5 .. 2K+w+4 back), K timed + w single-stream replays (2K+2w+5 .. 3K+2w+4 back))"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "knn_grid_ranges"
