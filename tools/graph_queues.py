@@ -1,12 +1,13 @@
 """One forked hipGraph replay of bench.py from a rocprofv3 kernel trace, with the hardware queue of every kernel: the graph executor
 spreads a graph over very few queues, and which branch shares a queue with which decides what waits.  Development aid.
-usage: graph_queues.py <kernel_trace.csv> [steps back from the last marker, default 18 = a forked replay of `bench.py --steps 10
---warmup 3`; 31 = a single-stream replay of the same run (see tools/step_sequence.py for the layout)]"""
+usage: graph_queues.py <kernel_trace.csv> [steps back from the last marker, default 19 = a forked replay of `bench.py --steps 10
+--warmup 3`; 32 = a single-stream replay of the same run (18 and 31 are the last replays of their forms, followed by the
+kernels of the after-timing check (see tools/step_sequence.py for the layout)]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "knn_grid_ranges" in r["Kernel_Name"]]
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 18
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 19
 a, b = idx[-2 - back] - 5, idx[-1 - back] - 5        # a replay starts ~5 kernels before its marker (copy, K = 1 search, mesh / stem heads)
 t0 = int(rows[a]["Start_Timestamp"])
 busy = {}
