@@ -200,7 +200,7 @@ class FFB6DEmb(nn.Module):
         p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)
         return fuse_layer(torch.cat((rgb_emb0, p2r_emb), dim=1))
 
-    def forward(self, inputs, end_points=None, parts=False, side_first=None):
+    def forward(self, inputs, end_points=None, parts=False, side_first=None, stage_hook=None):
         """-> f32[B,128,N] (ffb6d.py:285: cat of the 64 image channels at the chosen pixels and the 64 point channels); parts=True
         returns the two halves un-concatenated, for a consumer that reads them in place (the fused per-point heads)."""
         if fused_eval(inputs["rgb"], self):
@@ -235,9 +235,9 @@ class FFB6DEmb(nn.Module):
         from . import pyramid as _pyr
         overlap = settings.USE_SIDE_STREAMS and "point" in settings.SIDE_PARTS and fused_eval(inputs["rgb"], self)
         if overlap and settings.USE_TWO_STREAM_PIPELINE:
-            return self._forward_two_streams(inputs, rgb_emb, parts, side_first)
-        if side_first is not None:
-            raise RuntimeError("side_first is a hook of the two-stream pipeline")
+            return self._forward_two_streams(inputs, rgb_emb, parts, side_first, stage_hook)
+        if side_first is not None or stage_hook is not None:
+            raise RuntimeError("side_first / stage_hook are hooks of the two-stream pipeline")
         if not overlap:
             _pyr.wait_ready(inputs)
         p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
@@ -310,7 +310,7 @@ class FFB6DEmb(nn.Module):
             return rgb_emb_c, p_emb
         return torch.cat([rgb_emb_c, p_emb], dim=1)
 
-    def _forward_two_streams(self, inputs, rgb_emb, parts, side_first=None):
+    def _forward_two_streams(self, inputs, rgb_emb, parts, side_first=None, stage_hook=None):
         """The inference forward as a two-stream pipeline (settings.USE_SIDE_STREAMS): the IMAGE stream (the current one) runs the
         trunk / up stages and the point-to-pixel fusions, the POINT stream (side stream 0) the RandLA blocks, the decoder layers and the
         pixel-to-point fusions.  Per stage each stream waits ONCE for the other's product (an event): the point stream for the image
@@ -344,6 +344,9 @@ class FFB6DEmb(nn.Module):
             p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)  # [B,8,N,1]
         ds_emb = []
         for i_ds in range(4):
+            if stage_hook is not None and stage_hook[0] == i_ds:
+                stage_hook[1]()                                               # independent work forked from here (the mesh branch): in a
+                                                                              # hipGraph its nodes then sit in front of this stage's
             rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
             ev_rgb0 = event(M)
             bs, c, hr, wr = rgb_emb0.size()

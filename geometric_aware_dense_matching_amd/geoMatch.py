@@ -196,6 +196,21 @@ class GeoMatch(nn.Module):
                 rgbd_emb = self.pcd_emb(inputs, parts=heads is not None, side_first=lambda: box.append(self.mesh_features()))
                 mesh_features = box[0]
                 mesh_features.record_stream(torch.cuda.current_stream(rgb.device))
+            elif (settings.MESH_FORK_AT >= 0 and isinstance(self.pcd_emb, FFB6DEmb) and settings.USE_TWO_STREAM_PIPELINE and "point" in settings.SIDE_PARTS
+                  and heads is not None):
+                # enqueued in front of encoder stage MESH_FORK_AT of the image stream (it only waits for an event recorded at the top, so
+                # in a hipGraph it is still a root): its nodes then sit beside that stage's convolutions instead of at the step's end
+                ev0 = torch.cuda.Event()
+                ev0.record(torch.cuda.current_stream(rgb.device))
+                box = []
+
+                def _mesh_fork():
+                    with ops.fork(rgb.device, 1, start=ev0) as f:
+                        mf = self.mesh_features()
+                        mr = ops.match_pack(mf, ops.MATCH_BF16X3) if settings.PACK_MESH_ROWS else None
+                    box.append((f, mf, mr))
+                rgbd_emb = self.pcd_emb(inputs, parts=True, stage_hook=(settings.MESH_FORK_AT, _mesh_fork))
+                late_join, mesh_features, mesh_rows = box[0]
             elif settings.MESH_FORK_LATE:
                 # enqueued BEHIND the embedding (it only waits for an event recorded before it): in a hipGraph the branch is still a
                 # root, but the executor -- which spreads a graph over very few hardware queues, in node order -- then keeps the image

@@ -69,6 +69,7 @@ USE_FUSED_ADAM = _flag("GDM_FUSED_ADAM")
 USE_PACKED_PRODUCERS = _flag("GDM_PACKED_PRODUCERS")     # psp_combine / the up-conv gather write the next GEMM's packed operand themselves
 USE_TWO_STREAM_PIPELINE = _flag("GDM_TWO_STREAM_PIPELINE")     # with USE_SIDE_STREAMS: image / point streams run ahead of each other, one event per stage and direction
 MESH_FORK_LATE = os.environ.get("GDM_MESH_FORK_LATE", "1") != "0"       # with USE_SIDE_STREAMS: the mesh fork is enqueued behind the embedding
+MESH_FORK_AT = int(os.environ.get("GDM_MESH_FORK_AT", "-1"))          # with USE_SIDE_STREAMS + the two-stream pipeline: the mesh fork is enqueued in front of encoder stage k (0..3) of the image stream; -1 = MESH_FORK_LATE decides
 MESH_ON_POINT_STREAM = os.environ.get("GDM_MESH_ON_POINT_STREAM", "0") == "1"   # development: the mesh branch at the head of the point stream
 PACK_MESH_ROWS = os.environ.get("GDM_PACK_MESH_ROWS", "1") != "0"         # with USE_SIDE_STREAMS: the model descriptors' matching rows are packed inside the mesh fork
 SPLIT_HEADS = os.environ.get("GDM_SPLIT_HEADS", "0") == "1"               # development: with USE_SIDE_STREAMS and forward(defer_seg=True) the heads run as two launches (measured: no gain, the arg-max kernel fills the chip)
