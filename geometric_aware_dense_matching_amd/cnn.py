@@ -205,22 +205,37 @@ class PSPModule(nn.Module):
             # no full-resolution priors
             ms, wf = self._split_weights()
             B, Cin = feats.shape[0], feats.shape[1]
-            if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
-                wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
-                g = ops.gemm_bf16x3_map(feats, wpk, co)                   # reads layer4's packed output when it is there
+            def full_res():
+                if settings.USE_MFMA_GEMM and ops.gemm_supported(Cin, wf.shape[0], h * w):
+                    wpk, co = cached_gemm_weight(self, "wf", wf, (self.bottleneck.weight,))
+                    return ops.gemm_bf16x3_map(feats, wpk, co)               # reads layer4's packed output when it is there
+                return ops.wx(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
+
+            def priors():
+                sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
+                pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w) else None
+                ys = []
+                mts = self._split_weights_t(ms) if settings.USE_POINTWISE else None
+                for k, (st, m) in enumerate(zip(self.stages, ms)):
+                    p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
+                    s_ = p.shape[2]
+                    if mts is not None:
+                        ys.append(ops.pointwise([p.reshape(B, Cin, s_ * s_)], mts[k]).view(B, -1, s_, s_))   # M_k . pool_k(f): own kernel
+                    else:
+                        ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
+                return ys
+
+            if settings.USE_SIDE_STREAMS and "psp" in settings.SIDE_PARTS and not torch.is_grad_enabled():
+                # the pools and the four prior products (five launches on a few hundred points) beside the full-resolution GEMM: both read
+                # the same map and meet in psp_combine -- same kernels on the same operands as the sequential order
+                with ops.fork(feats.device, 3) as f:           # 0 = point branch, 1 = mesh branch, 2 = pyramid
+                    f.use(feats)
+                    ys = priors()
+                g = full_res()
+                f.join(*ys)
             else:
-                g = ops.wx(wf, feats.reshape(B, Cin, h * w)).view(B, -1, h, w)
-            sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
-            pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w) else None
-            ys = []
-            mts = self._split_weights_t(ms) if settings.USE_POINTWISE else None
-            for k, (st, m) in enumerate(zip(self.stages, ms)):
-                p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
-                s_ = p.shape[2]
-                if mts is not None:
-                    ys.append(ops.pointwise([p.reshape(B, Cin, s_ * s_)], mts[k]).view(B, -1, s_, s_))   # M_k . pool_k(f): own kernel
-                else:
-                    ys.append(ops.wx(m, p.reshape(B, Cin, s_ * s_)).view(B, -1, s_, s_))
+                g = full_res()
+                ys = priors()
             return ops.psp_combine(g, ys, self.bottleneck.bias, packed=settings.USE_MFMA_GEMM and settings.USE_PACKED_PRODUCERS)
         sizes = [st[0].output_size[0] if isinstance(st[0].output_size, (tuple, list)) else st[0].output_size for st in self.stages]
         if (settings.USE_SPLIT_PSP_TRAIN and feats.is_cuda and feats.dtype == torch.float32 and sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w)

@@ -67,25 +67,55 @@ def pose_errors(RT_est, RT_gt, model_xyz, K, symmetric=False, sym_rots=None):
     return dict(ad=ad, re=re, te=te, proj=proj)
 
 
+PRECISION_METRICS = [m for m in METRICS if m != "ad_0.1"]          # evaluator.py:513-529: the precision table has no absolute 10 cm line
+
+
 class RecallTable:
     """The recall / error bookkeeping of evaluator.py:342-463.  update() takes the errors of a batch of instances of one object,
     missing() records ground truths without a prediction (every recall 0, no error entry: :359-362), table() / format() give the
-    reference's table: one line per metric with the per-object mean recall x 100 and the mean over objects, then mean re / te."""
+    reference's table: one line per metric with the per-object mean recall x 100 and the mean over objects, then mean re / te.
 
-    def __init__(self):
+    precision=True is `_eval_predictions_precision` (evaluator.py:466-660, "precision as in the DPOD paper"): ground truths without a
+    prediction are IGNORED instead of counted as misses (:549-551) and the metric list drops "ad_0.1"; everything else is the same
+    bookkeeping.  dump() writes what the reference leaves in its output directory (:449-455 / :647-660)."""
+
+    def __init__(self, precision=False):
+        self.precision = bool(precision)
+        self.metrics = PRECISION_METRICS if self.precision else METRICS
         self.recalls = OrderedDict()
         self.errors = OrderedDict()
 
     def _slot(self, obj_name):
         if obj_name not in self.recalls:
-            self.recalls[obj_name] = OrderedDict((m, []) for m in METRICS)
+            self.recalls[obj_name] = OrderedDict((m, []) for m in self.metrics)
             self.errors[obj_name] = OrderedDict((e, []) for e in ("ad", "re", "te", "proj"))
         return self.recalls[obj_name], self.errors[obj_name]
 
     def missing(self, obj_name, count=1):
         rec, _ = self._slot(obj_name)
-        for m in METRICS:
+        if self.precision:
+            return                                                      # "NOTE: just ignore undetected" (evaluator.py:549-551)
+        for m in self.metrics:
             rec[m] += [0.0] * count
+
+    def dump(self, output_dir, dataset_name, method_name=""):
+        """errors / recalls as pickles and the table as text, under the reference's file names: `_{dataset}_errors.pkl`,
+        `_{dataset}_recalls.pkl`, `_{dataset}_tab.txt` (evaluator.py:449-455); the precision variant prefixes the method name and
+        says `precisions` (:647-660).  The reference writes the pickles through mmcv.dump, which is pickle for a .pkl path."""
+        import os
+        import pickle
+        os.makedirs(output_dir, exist_ok=True)
+        kind = "precisions" if self.precision else "recalls"
+        stem = os.path.join(output_dir, "%s_%s" % (method_name, dataset_name))
+        paths = (stem + "_errors.pkl", stem + "_%s.pkl" % kind, stem + ("_tab_precisions.txt" if self.precision else "_tab.txt"))
+        with open(paths[0], "wb") as f:
+            pickle.dump(self.errors, f)
+        with open(paths[1], "wb") as f:
+            pickle.dump(self.recalls, f)
+        with open(paths[2], "w") as f:
+            f.write("%s\n" % self.format())
+        return paths
+
 
     def update(self, obj_name, errors, diameter):
         """errors: pose_errors() output (tensors or arrays of equal length); diameter in metres."""
@@ -98,13 +128,13 @@ class RecallTable:
                  "rete_2": (re < 2) & (te < 0.02), "rete_5": (re < 5) & (te < 0.05), "rete_10": (re < 10) & (te < 0.1),
                  "re_2": re < 2, "re_5": re < 5, "re_10": re < 10, "te_2": te < 0.02, "te_5": te < 0.05, "te_10": te < 0.1,
                  "proj_2": proj < 2, "proj_5": proj < 5, "proj_10": proj < 10}           # evaluator.py:408-427
-        for m in METRICS:
+        for m in self.metrics:
             rec[m] += flags[m].astype(np.float64).tolist()
 
     def table(self):
         obj_names = sorted(self.recalls.keys())
         tab = [["objects"] + obj_names + ["Avg(%d)" % len(obj_names)]]
-        for m in METRICS:
+        for m in self.metrics:
             line, vals = [m], []
             for o in obj_names:
                 res = self.recalls[o][m]
@@ -128,3 +158,37 @@ class RecallTable:
         tab = [[str(c) for c in row] for row in self.table()]
         width = [max(len(r[i]) for r in tab if i < len(r)) for i in range(max(len(r) for r in tab))]
         return "\n".join("  ".join(c.ljust(width[i]) for i, c in enumerate(r)).rstrip() for r in tab)
+
+
+class BopCsv:
+    """The BOP-toolkit result file the reference writes while it walks the predictions (evaluator.py:341,365-373,429-431): header
+    `scene_id,im_id,obj_id,score,R,t,time`, one line per predicted instance with R row-major and t in MILLIMETRES, both space
+    separated, score and time -1.  `file_name` is the reference's prediction key "scene/…/im_id" (:366-367)."""
+
+    HEADER = "scene_id,im_id,obj_id,score,R,t,time"
+
+    def __init__(self):
+        self.lines = [self.HEADER]
+
+    def add(self, file_name, obj_id, R, t, score=-1, time=-1):
+        R = np.asarray(R.detach().cpu() if torch.is_tensor(R) else R, dtype=np.float64).reshape(3, 3)
+        t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float64).reshape(-1)
+        parts = str(file_name).split("/")
+        self.lines.append("{scene_id},{im_id},{obj_id},{score},{R},{t},{time}".format(
+            scene_id=int(parts[0]), im_id=parts[-1], obj_id=int(obj_id), score=score,
+            R=" ".join(map(str, R.flatten().tolist())), t=" ".join(map(str, (t * 1000).flatten().tolist())), time=time))
+
+    def add_batch(self, file_names, obj_id, RT):
+        """RT [n,3,4] (pose.solve_poses / infer.run_multi_object output), metres."""
+        RT = RT.detach().cpu().double().numpy() if torch.is_tensor(RT) else np.asarray(RT, dtype=np.float64)
+        for name, rt in zip(file_names, RT):
+            self.add(name, obj_id, rt[:, :3], rt[:, 3])
+
+    def write(self, path):
+        import os
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        with open(path, "w") as f:
+            f.write("\n".join(self.lines))                             # no trailing newline, as the reference (:430-431)
+        return path

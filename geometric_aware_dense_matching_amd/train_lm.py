@@ -73,6 +73,8 @@ def build_parser():
     p.add_argument("--log-every", type=int, default=100)
     p.add_argument("--max-iters", type=int, default=None)
     p.add_argument("--single-object", action="store_true", help="test: only -cls_id instead of every object of the dataset")
+    p.add_argument("--eval-output", dest="eval_output", type=str, default=None,
+                   help="test: directory for the evaluator's files -- BOP result csv, error / recall / precision pickles, table text")
     p.add_argument("--graph-batch1", action="store_true",
                    help="test: per-object hipGraph replay for single-instance groups (a batch-1 eager step is launch-bound)")
     p.add_argument("--objects-across-gpus", action="store_true",
@@ -348,6 +350,9 @@ def test(args):
     # is computed on the device per object group and the reference's recall table is printed at the end
     from . import evaluation
     table = evaluation.RecallTable()
+    prec_table = evaluation.RecallTable(precision=True)      # evaluator.py:466-660, written beside the recall table with --eval_output
+    bop = evaluation.BopCsv()                                # evaluator.py:341,365-373: one line per predicted instance
+    n_seen = 0
     sym_names = set(ds.get("sym_objs", ()))                 # config/*_cfg.py SYM_OBJS: object NAMES
     with torch.no_grad():
         for batch in loader:
@@ -373,10 +378,26 @@ def test(args):
                                                  Kcam[rows] if Kcam.dim() == 3 else Kcam, symmetric=obj_name_of(ds, cid) in sym_names,
                                                  sym_rots=getattr(model_dict[cid].model_emb, "sym_rots", None))
                     table.update(obj_name_of(ds, cid), err, ds["diameters"][cid] / 1000.0)
+                    prec_table.update(obj_name_of(ds, cid), err, ds["diameters"][cid] / 1000.0)
+            # the reference keys a prediction by "scene/.../im_id" (evaluator.py:366-367); a loader without these fields gets the running
+            # instance number as im_id of scene 0
+            for i, cid in enumerate(cls):
+                scene = int(batch["scene_id"][i]) if "scene_id" in batch else 0
+                im = int(batch["im_id"][i]) if "im_id" in batch else n_seen + i
+                bop.add("%06d/%06d" % (scene, im), cid, out["RT"][i, :, :3], out["RT"][i, :, 3])
+            n_seen += len(cls)
     if table.recalls:
         test.last_table = table
         if args.local_rank == 0:
             print(table.format())
+    if getattr(args, "eval_output", None) and args.local_rank == 0:
+        # what the reference's evaluator leaves behind: the BOP result csv (:429-431) and, when ground truth was there, the error /
+        # recall pickles and the table text of both variants (:449-455, :647-660)
+        written = [bop.write(os.path.join(args.eval_output, "%s_%s-test.csv" % (args.model_variant, args.dataset_name)))]
+        if table.recalls:
+            written += list(table.dump(args.eval_output, args.dataset_name + "_test"))
+            written += list(prec_table.dump(args.eval_output, args.dataset_name + "_test", method_name=args.model_variant))
+        test.last_outputs = written
     return results
 
 

@@ -408,7 +408,7 @@ def test_timed_configuration_bit_exact_across_launch_forms(headline_model):
                 same(ref, s, "graph replay %d (forks off)" % i)
             # (3) forks on: eager and replayed
             settings.USE_SIDE_STREAMS = True
-            settings.SIDE_PARTS = ["mesh", "point", "pyr"]
+            settings.SIDE_PARTS = ["mesh", "point", "pyr", "psp"]
             same(ref, snap(_bench_step(model, inputs, cld, dpt_xyz, B)), "eager step with side-stream forks")
             for i, s in enumerate(graphed("on")):
                 same(ref, s, "graph replay %d (forks on)" % i)

@@ -95,12 +95,25 @@ def test_trainer_runs_saves_and_resumes(tmp_path):
         assert torch.equal(a, b), k
 
 
-def test_test_entry_point_runs():
+def test_test_entry_point_runs(tmp_path):
     from geometric_aware_dense_matching_amd import train_lm
-    args = train_lm.build_parser().parse_args("--gpus=0 -state=test -cls_id=1 --single-object --batch-size 2 --n-points 1024 --n-mesh 512 "
-                                              "--synthetic-items 4".split())
+    args = train_lm.build_parser().parse_args(("--gpus=0 -state=test -cls_id=1 --single-object --batch-size 2 --n-points 1024 --n-mesh 512 "
+                                               "--synthetic-items 4 --eval-output %s" % tmp_path).split())
     res = train_lm.test(args)
     assert len(res) == 2 and res[0]["best_idx"].shape == (2, 1024) and int(res[0]["best_idx"].max()) < 512
+    # the evaluator's files (evaluator.py:341,365-373,429-431): one csv line per predicted instance, R row-major, t in millimetres
+    out = train_lm.test.last_outputs
+    lines = open(out[0]).read().split("\n")
+    assert os.path.basename(out[0]) == "ffb6d_lmo-test.csv" and lines[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(lines) == 1 + 4
+    f = lines[2].split(",")
+    assert f[:4] == ["0", "000001", "1", "-1"] and f[6] == "-1"
+    assert np.allclose(np.array(f[4].split(" "), dtype=np.float64).reshape(3, 3), res[0]["RT"][1, :, :3].double().numpy(), atol=0)
+    assert np.allclose(np.array(f[5].split(" "), dtype=np.float64), 1000 * res[0]["RT"][1, :, 3].double().numpy(), atol=0)
+    if len(out) > 1:                                       # the synthetic loader carries ground-truth poses: both tables were dumped
+        names = [os.path.basename(p) for p in out[1:]]
+        assert names == ["_lmo_test_errors.pkl", "_lmo_test_recalls.pkl", "_lmo_test_tab.txt", "ffb6d_lmo_test_errors.pkl",
+                         "ffb6d_lmo_test_precisions.pkl", "ffb6d_lmo_test_tab_precisions.txt"]
+        assert len(open(out[3]).read().splitlines()) == 19 and len(open(out[6]).read().splitlines()) == 18
 
 
 @pytest.mark.parametrize("entry,cls_id,extra", [("train_lm", 5, ""), ("train_ycb", 21, ""), ("train_ycb", 16, "--model-variant dgcnn")])

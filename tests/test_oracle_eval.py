@@ -70,3 +70,54 @@ def test_settings_switch_lists_are_consistent():
     doc = settings.__doc__
     for name in settings.ALL_SWITCHES:
         assert name in doc, "settings.py's table does not describe %s" % name
+
+
+def test_precision_variant_ignores_undetected_and_has_no_absolute_ad_line():
+    """evaluator.py:466-660 (`_eval_predictions_precision`): same flags, ground truths without a prediction skipped (:549-551), no
+    "ad_0.1" line (:513-529)."""
+    from geometric_aware_dense_matching_amd import evaluation
+    rs = np.random.RandomState(5)
+    e = dict(ad=np.abs(rs.randn(7)) * 0.02, re=np.abs(rs.randn(7)) * 6, te=np.abs(rs.randn(7)) * 0.06, proj=np.abs(rs.randn(7)) * 6)
+    rec, prec = evaluation.RecallTable(), evaluation.RecallTable(precision=True)
+    for t in (rec, prec):
+        t.update("ape", e, 0.102)
+        t.missing("ape", 7)
+    assert [r[0] for r in prec.table()[1:]] == [m for m in eval_ref.METRICS if m != "ad_0.1"] + ["re", "te"]
+    for m in evaluation.PRECISION_METRICS:
+        assert len(prec.recalls["ape"][m]) == 7 and len(rec.recalls["ape"][m]) == 14
+        assert abs(np.mean(prec.recalls["ape"][m]) - 2 * np.mean(rec.recalls["ape"][m])) < 1e-12      # half of the recall's entries are misses
+        want = [eval_ref.recall_flags(e["ad"][i], e["re"][i], e["te"][i], e["proj"][i], 0.102)[m] for i in range(7)]
+        assert prec.recalls["ape"][m] == want
+
+
+def test_bop_csv_lines_and_result_dumps(tmp_path):
+    """evaluator.py:341,365-373,429-431 (csv) and :449-455 / :647-660 (pickles + table text)."""
+    import pickle
+    from geometric_aware_dense_matching_amd import evaluation
+    rs = np.random.RandomState(7)
+    R = np.linalg.qr(rs.randn(3, 3))[0]
+    t = rs.randn(3) * 0.3
+    csv = evaluation.BopCsv()
+    csv.add("000002/rgb/000431", 5, R, t)
+    RT = np.concatenate([R, t[:, None]], 1)[None].repeat(2, 0)
+    csv.add_batch(["000048/000007", "000048/000012"], 9, RT)
+    assert csv.lines[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(csv.lines) == 4
+    want = "{},{},{},{},{},{},{}".format(2, "000431", 5, -1, " ".join(map(str, R.flatten().tolist())),
+                                       " ".join(map(str, (t * 1000).flatten().tolist())), -1)           # the reference's format call
+    assert csv.lines[1] == want
+    f = csv.lines[3].split(",")
+    assert f[:4] == ["48", "000012", "9", "-1"] and len(f[4].split(" ")) == 9 and len(f[5].split(" ")) == 3 and f[6] == "-1"
+    assert np.allclose(np.array(f[5].split(" "), dtype=np.float64), t * 1000, rtol=0, atol=0)
+    path = csv.write(str(tmp_path / "bop" / "gt_ycbv-test.csv"))
+    text = open(path).read()
+    assert text.split("\n") == csv.lines and not text.endswith("\n")
+    tab = evaluation.RecallTable()
+    tab.update("ape", dict(ad=np.array([0.001]), re=np.array([1.0]), te=np.array([0.01]), proj=np.array([1.0])), 0.102)
+    pe, pr, pt = tab.dump(str(tmp_path), "lmo_test")
+    assert [os.path.basename(p) for p in (pe, pr, pt)] == ["_lmo_test_errors.pkl", "_lmo_test_recalls.pkl", "_lmo_test_tab.txt"]
+    assert pickle.load(open(pr, "rb"))["ape"]["ad_2"] == [1.0] and pickle.load(open(pe, "rb"))["ape"]["re"] == [1.0]
+    assert open(pt).read() == tab.format() + "\n"
+    pp = evaluation.RecallTable(precision=True)
+    pp.update("ape", dict(ad=np.array([0.001]), re=np.array([1.0]), te=np.array([0.01]), proj=np.array([1.0])), 0.102)
+    names = [os.path.basename(p) for p in pp.dump(str(tmp_path), "lmo_test", method_name="geomatch")]
+    assert names == ["geomatch_lmo_test_errors.pkl", "geomatch_lmo_test_precisions.pkl", "geomatch_lmo_test_tab_precisions.txt"]

@@ -71,7 +71,7 @@ def main():
     with torch.no_grad():
         for cfg in args.configs.split(","):
             settings.USE_SIDE_STREAMS = cfg != "off"
-            settings.SIDE_PARTS = ["mesh", "point", "pyr"] if cfg == "all" else cfg.split("+")
+            settings.SIDE_PARTS = ["mesh", "point", "pyr", "psp"] if cfg == "all" else cfg.split("+")
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
