@@ -130,6 +130,11 @@ class PwSeg(ctypes.Structure):
     _fields_ = [("x", _vp), ("idx", _vp), ("C", ctypes.c_int32), ("n_src", ctypes.c_int32)]
 
 
+class PwJob(ctypes.Structure):
+    """gdm_pw_job (include/gdm.h)."""
+    _fields_ = [("x", _vp), ("wt", _vp), ("out", _vp), ("n", ctypes.c_int32)]
+
+
 class CopyJob(ctypes.Structure):
     """gdm_copy_job (include/gdm.h)."""
     _fields_ = [("dst", _vp), ("src", _vp), ("sb", ctypes.c_int64), ("s1", ctypes.c_int64), ("s2", ctypes.c_int64),
@@ -145,6 +150,8 @@ SIGNATURES["gdm_wgrad_pack_x_hip"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_wgrad_pack_go_hip"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_conv1x1_packed_wb_hip"] = (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_gather_add_affine_act2_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp])
+SIGNATURES["gdm_spline_direct3_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+SIGNATURES["gdm_spline_pairs_aggregate3_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
 SIGNATURES["gdm_spline_direct2_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["gdm_spline_pairs_aggregate2_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["gdm_wgrad_x1_bytes"] = (_sz, [_i, _i, _i])
@@ -153,6 +160,7 @@ SIGNATURES["gdm_wgrad_direct_hip"] = (_i, [_vp, ctypes.c_long, _vp, ctypes.c_lon
 SIGNATURES["gdm_mfma_probe_hip"] = (_i, [_i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_mfma_probe_lds_hip"] = (_i, [_i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_copy_jobs_hip"] = (_i, [ctypes.POINTER(CopyJob), _i, _vp])
+SIGNATURES["gdm_pointwise_jobs_hip"] = (_i, [ctypes.POINTER(PwJob), _i, _i, _i, _i, _vp])
 SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 
 _lib = None

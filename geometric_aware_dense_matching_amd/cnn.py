@@ -216,6 +216,10 @@ class PSPModule(nn.Module):
                 pools = ops.psp_pools(feats) if sizes == [1, 2, 3, 6] and ops.psp_pools_supported(h, w) else None
                 ys = []
                 mts = self._split_weights_t(ms) if settings.USE_POINTWISE else None
+                if mts is not None and pools is not None and settings.USE_PSP_JOBS and Cin >= 32:
+                    # the four prior products M_k . pool_k(f) in one launch (each alone is a latency-bound launch on 16 .. 576 points)
+                    outs = ops.pointwise_jobs([p.reshape(B, Cin, -1) for p in pools], mts)
+                    return [o.view(B, -1, p.shape[2], p.shape[3]) for o, p in zip(outs, pools)]
                 for k, (st, m) in enumerate(zip(self.stages, ms)):
                     p = pools[k] if pools is not None else st[0](feats)        # adaptive average pool to s x s
                     s_ = p.shape[2]

@@ -409,6 +409,31 @@ __global__ __launch_bounds__(GB) void seg_mask_kernel(const float* __restrict__ 
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&count[b], __popcll(bal));
 }
 
+// The same with ONE workgroup per crop (N up to a few 10^4 points): the count is a block reduction written once -- no memset node in
+// front of the kernel, no atomics.
+__global__ __launch_bounds__(1024) void seg_mask_crop_kernel(const float* __restrict__ seg, int N, uint8_t* __restrict__ mask,
+                                                             int32_t* __restrict__ count)
+{
+    __shared__ int wsum[16];
+    const int b = blockIdx.x;
+    const float* s0p = seg + (long)b * 2 * N;
+    const float* s1p = s0p + N;
+    int mine = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const int sel = s1p[i] > s0p[i] ? 1 : 0;        // torch.argmax: first maximum wins on ties -> class 0
+        mask[(long)b * N + i] = (uint8_t)sel;
+        mine += sel;
+    }
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        count[b] = t;
+    }
+}
+
 } // namespace
 
 #define STREAM(s) ((hipStream_t)(s))
@@ -559,6 +584,10 @@ extern "C" int gdm_seg_mask_hip(const float* seg, int B, int N, uint8_t* mask, i
 {
     GDM_CHECK_ARG(seg && mask && count, "gdm_seg_mask_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && N >= 1 && B <= 65535, "gdm_seg_mask_hip: bad shape");
+    if (N <= 65536) {
+        hipLaunchKernelGGL(seg_mask_crop_kernel, dim3(B), dim3(1024), 0, STREAM(stream), seg, N, mask, count);
+        return gdm_launch_status("seg_mask_crop_kernel");
+    }
     GDM_HIP(hipMemsetAsync(count, 0, sizeof(int32_t) * B, STREAM(stream)));
     hipLaunchKernelGGL(seg_mask_kernel, dim3(gdm_cdiv(N, GB), B), dim3(GB), 0, STREAM(stream), seg, N, mask, count);
     return gdm_launch_status("seg_mask_kernel");

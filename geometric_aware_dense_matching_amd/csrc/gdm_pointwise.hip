@@ -283,14 +283,12 @@ typedef __attribute__((ext_vector_type(4))) float pw_f32x4;
 // p0 + 16 g + (l & 15), so ONE 16-byte load per lane fetches a K row's values for all four blocks (a wave-wide dword load costs the
 // texture path what a dwordx4 one does: 2 load instructions per step instead of 5), and the four blocks' results for one (row group,
 // r) are four consecutive points = one 16-byte store
+// one tile of 64 points x 16 channels (points from p0, channels from c0) by the KS waves of the workgroup; `red`: [KS][16][64] floats of LDS
 template <int KS, bool VEC>
-__global__ __launch_bounds__(KS * 64) void pointwise_mfma_kernel(const PwArgs a)
+__device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, const int c0, float (*red)[16][64])
 {
-    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? KS : 1][16][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, kq = lane >> 4;
-    const long p0 = (long)blockIdx.x * PT;
-    const int c0 = (int)blockIdx.y * 16;
     const int n = a.n, Cout = a.Cout, K = a.K;
     const int kpart = (((K + KS - 1) / KS + 3) / 4) * 4;
     const int kbeg = wave * kpart, kend = min(K, kbeg + kpart);
@@ -471,6 +469,39 @@ __global__ __launch_bounds__(KS * 64) void pointwise_mfma_kernel(const PwArgs a)
     }
 }
 
+template <int KS, bool VEC>
+__global__ __launch_bounds__(KS * 64) void pointwise_mfma_kernel(const PwArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? KS : 1][16][64];
+    pw_mfma_tile<KS, VEC>(a, (long)blockIdx.x * PT, (int)blockIdx.y * 16, red);
+}
+
+// Up to four INDEPENDENT layers of equal K and Cout in one launch (the four prior products M_k . pool_k(f) of the pyramid-pooling
+// module, pspnet.py:17-31: 16 ... 576 points each, every one a latency-bound launch of its own): the tiles of job j are the blocks
+// [e_{j-1}, e_j) of the grid's x axis; each job runs exactly the tile function of pointwise_mfma_kernel with the same K split, so
+// the results are bit-identical to the separate launches.  The four argument blocks are four kernel parameters (statically
+// addressed: indexing an array of them by blockIdx would copy the block to scratch memory).
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void pointwise_mfma_jobs_kernel(const PwArgs a0, const PwArgs a1, const PwArgs a2, const PwArgs a3,
+                                                                      int e0, int e1, int e2, int vecmask)
+{
+    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? KS : 1][16][64];
+    const int bx = (int)blockIdx.x, c0 = (int)blockIdx.y * 16;
+    if (bx < e0) {
+        if (vecmask & 1) pw_mfma_tile<KS, true>(a0, (long)bx * PT, c0, red);
+        else pw_mfma_tile<KS, false>(a0, (long)bx * PT, c0, red);
+    } else if (bx < e1) {
+        if (vecmask & 2) pw_mfma_tile<KS, true>(a1, (long)(bx - e0) * PT, c0, red);
+        else pw_mfma_tile<KS, false>(a1, (long)(bx - e0) * PT, c0, red);
+    } else if (bx < e2) {
+        if (vecmask & 4) pw_mfma_tile<KS, true>(a2, (long)(bx - e1) * PT, c0, red);
+        else pw_mfma_tile<KS, false>(a2, (long)(bx - e1) * PT, c0, red);
+    } else {
+        if (vecmask & 8) pw_mfma_tile<KS, true>(a3, (long)(bx - e2) * PT, c0, red);
+        else pw_mfma_tile<KS, false>(a3, (long)(bx - e2) * PT, c0, red);
+    }
+}
+
 bool seg_ok(const gdm_pw_seg& s, int n)
 {
     return s.x && s.C >= 1 && s.n_src >= 1 && (s.idx || s.n_src == n);
@@ -554,4 +585,62 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
     else GDM_PW_LAUNCH(8, 2, 64);
 #undef GDM_PW_LAUNCH
     return gdm_launch_status("pointwise_kernel");
+}
+
+extern "C" int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, int K, int Cout, void* stream)
+{
+    GDM_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4, "gdm_pointwise_jobs_hip: njobs=%d not in [1,4]", njobs);
+    GDM_CHECK_ARG(B >= 1 && K >= 32 && Cout >= 1 && gdm_cdiv(Cout, 16) <= 65535, "gdm_pointwise_jobs_hip: bad shape B=%d K=%d Cout=%d", B, K, Cout);
+    PwArgs a[4];
+    int ends[4];
+    int vecmask = 0;
+    long tiles = 0;
+    for (int j = 0; j < 4; ++j) {
+        const gdm_pw_job& jb = jobs[j < njobs ? j : njobs - 1];
+        if (j < njobs) {
+            GDM_CHECK_ARG(jb.x && jb.wt && jb.out && jb.n >= 1, "gdm_pointwise_jobs_hip: job %d: NULL pointer or n=%d", j, jb.n);
+            GDM_CHECK_ARG(((uintptr_t)jb.out & 15) == 0, "gdm_pointwise_jobs_hip: job %d: out must be 16-byte aligned", j);
+        }
+        for (int s = 0; s < MAXSEG; ++s) a[j].seg[s] = PwSegDev{nullptr, nullptr, 0, 0};
+        a[j].seg[0] = PwSegDev{jb.x, nullptr, K, jb.n};
+        a[j].nseg = 1;
+        a[j].wt = jb.wt;
+        a[j].scale = nullptr;
+        a[j].shift = nullptr;
+        a[j].out = jb.out;
+        a[j].n = jb.n;
+        a[j].Cout = Cout;
+        a[j].outC = Cout;
+        a[j].out_c0 = 0;
+        a[j].point_major = 0;
+        a[j].act = 0;
+        a[j].slope = 0.f;
+        a[j].K = K;
+        a[j].total = (long)B * jb.n;
+        if (j < njobs) {
+            tiles += (a[j].total + PT - 1) / PT;
+            if (jb.n % 4 == 0 && ((uintptr_t)jb.x & 15) == 0 && !getenv("GDM_PW_NOVEC")) vecmask |= 1 << j;
+        }
+        ends[j] = (int)tiles;                                        // jobs past njobs own no blocks
+    }
+    GDM_CHECK_ARG(tiles <= 0x7fffffffL, "gdm_pointwise_jobs_hip: grid too large");
+    // the K split of gdm_pointwise_hip, chosen PER JOB there: the jobs launched together must agree with their separate launches bit for
+    // bit, so the split is the smallest any of them would take alone (a smaller job never takes fewer parts than a larger one)
+    int ks = 8;
+    for (int j = 0; j < njobs; ++j) {
+        const long tj = (a[j].total + PT - 1) / PT;
+        int kj = 1;
+        while (kj < 8 && K / (2 * kj) >= 16 && tj * gdm_cdiv(Cout, 16) * kj < 4096) kj *= 2;
+        GDM_CHECK_ARG(j == 0 || kj == ks, "gdm_pointwise_jobs_hip: job %d would split K into %d parts alone, job 0 into %d: launch them apart", j, kj, ks);
+        ks = kj;
+    }
+    const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, 16));
+    hipStream_t st = (hipStream_t)stream;
+#define GDM_PWJ(KSV) hipLaunchKernelGGL((pointwise_mfma_jobs_kernel<KSV>), grid, dim3(KSV * 64), 0, st, a[0], a[1], a[2], a[3], ends[0], ends[1], ends[2], vecmask)
+    if (ks == 1) GDM_PWJ(1);
+    else if (ks == 2) GDM_PWJ(2);
+    else if (ks == 4) GDM_PWJ(4);
+    else GDM_PWJ(8);
+#undef GDM_PWJ
+    return gdm_launch_status("pointwise_mfma_jobs_kernel");
 }

@@ -174,6 +174,21 @@ __global__ __launch_bounds__(128) void spline_direct_kernel(const float* __restr
     }
 }
 
+// The four channels [o, o+4) of vertex i as their half of a 16-byte group of the packed split-bf16 operand the next layer's grouped GEMM
+// reads (conv_pack_act_kernel's layout for a [1, C, 1, M] map: planes of 3 x (M + 2) zero-bordered pixels, hi plane q / lo plane 16 + q of
+// every 128-channel chunk, 8 channels = 16 bytes per pixel): the pack launch between two SplineConv layers is then not needed.
+__device__ __forceinline__ void spline_store_packed(unsigned char* __restrict__ out_pk, int M, int i, int o, const float4 r)
+{
+    const long plane = 3L * (M + 2);
+    const int chunk = o >> 7, q = (o & 127) >> 3, half = (o & 7) >> 2;
+    unsigned hi0, lo0, hi1, lo1;
+    gdm_split2(r.x, r.y, hi0, lo0);
+    gdm_split2(r.z, r.w, hi1, lo1);
+    unsigned char* p = out_pk + (((long)chunk * 32 + q) * plane + (M + 2) + i + 1) * 16 + half * 8;
+    *reinterpret_cast<uint2*>(p) = make_uint2(hi0, hi1);
+    *reinterpret_cast<uint2*>(p + 16 * plane * 16) = make_uint2(lo0, lo1);
+}
+
 // The same with FOUR output channels per thread (C % 4 == 0): the kernel is bound by its weight loads (4 edges x 8 corners x Cin rows
 // per output channel, L2 hits), and a 16-byte load costs the memory path what a 4-byte one does -- a quarter of the load instructions
 // and of the threads.  A 128-thread block owns 512 / C vertices.
@@ -182,7 +197,8 @@ __global__ __launch_bounds__(128) void spline_direct_vec_kernel(const float* __r
                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                                 const float* __restrict__ attr, const float* __restrict__ root_t,
                                                                 const float* __restrict__ bias, int M, int Cin, int C, int KS,
-                                                                float* __restrict__ out, float* __restrict__ out_t)
+                                                                float* __restrict__ out, float* __restrict__ out_t,
+                                                                unsigned char* __restrict__ out_pk)
 {
     const int tpv = C / 4;                                        // threads per vertex
     const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
@@ -251,6 +267,7 @@ __global__ __launch_bounds__(128) void spline_direct_vec_kernel(const float* __r
         out_t[(long)(o + 0) * M + i] = r.x; out_t[(long)(o + 1) * M + i] = r.y;
         out_t[(long)(o + 2) * M + i] = r.z; out_t[(long)(o + 3) * M + i] = r.w;
     }
+    if (out_pk) spline_store_packed(out_pk, M, i, o, r);
 }
 
 // Aggregation for the edge-grouped form: Y f32[R,128-wide rows of C] holds x_j . W[wi] for every (source, kernel index) pair that
@@ -285,7 +302,8 @@ template <bool RELU>
 __global__ __launch_bounds__(128) void spline_pairs_aggregate_vec_kernel(const float* __restrict__ Y, const int32_t* __restrict__ rowptr,
                                                                          const int32_t* __restrict__ pos, const float* __restrict__ basis,
                                                                          const float* __restrict__ root, const float* __restrict__ bias,
-                                                                         int M, int C, float* __restrict__ out, float* __restrict__ out_t)
+                                                                         int M, int C, float* __restrict__ out, float* __restrict__ out_t,
+                                                                         unsigned char* __restrict__ out_pk)
 {
     const int tpv = C / 4;
     const int i = blockIdx.x * (128 / tpv) + threadIdx.x / tpv;
@@ -320,31 +338,41 @@ __global__ __launch_bounds__(128) void spline_pairs_aggregate_vec_kernel(const f
         out_t[(long)(o + 0) * M + i] = r.x; out_t[(long)(o + 1) * M + i] = r.y;
         out_t[(long)(o + 2) * M + i] = r.z; out_t[(long)(o + 3) * M + i] = r.w;
     }
+    if (out_pk) spline_store_packed(out_pk, M, i, o, r);
 }
 
 } // namespace
 
-extern "C" int gdm_spline_pairs_aggregate2_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+extern "C" int gdm_spline_pairs_aggregate3_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
                                                const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t,
-                                               void* stream)
+                                               void* out_packed, void* stream)
 {
+    unsigned char* out_pk = (unsigned char*)out_packed;
     GDM_CHECK_ARG(Y && rowptr && pos && basis && (out || out_t), "gdm_spline_pairs_aggregate_hip: NULL pointer");
+    GDM_CHECK_ARG(!out_pk || (C % 128 == 0 && C <= 512), "gdm_spline_pairs_aggregate3_hip: the packed output needs C = 128, 256 or 512");
     GDM_CHECK_ARG(M >= 1 && C >= 1, "gdm_spline_pairs_aggregate_hip: bad shape");
     if (C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!root || ((uintptr_t)root & 15) == 0) &&
         (!bias || ((uintptr_t)bias & 15) == 0)) {
         const dim3 grid(gdm_cdiv(M, 128 / (C / 4)));
         if (relu)
-            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t);
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<true>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t, out_pk);
         else
-            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t);
+            hipLaunchKernelGGL(spline_pairs_aggregate_vec_kernel<false>, grid, dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, M, C, out, out_t, out_pk);
         return gdm_launch_status("spline_pairs_aggregate_vec_kernel");
     }
-    GDM_CHECK_ARG(out && !out_t, "gdm_spline_pairs_aggregate2_hip: the channel-major output needs C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
+    GDM_CHECK_ARG(out && !out_t && !out_pk, "gdm_spline_pairs_aggregate2_hip: the channel-major / packed outputs need C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
     if (relu)
         hipLaunchKernelGGL(spline_pairs_aggregate_kernel<true>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
     else
         hipLaunchKernelGGL(spline_pairs_aggregate_kernel<false>, dim3(M), dim3(128), 0, (hipStream_t)stream, Y, rowptr, pos, basis, root, bias, C, out);
     return gdm_launch_status("spline_pairs_aggregate_kernel");
+}
+
+extern "C" int gdm_spline_pairs_aggregate2_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                               const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t,
+                                               void* stream)
+{
+    return gdm_spline_pairs_aggregate3_hip(Y, rowptr, pos, basis, root, bias, M, C, relu, out, out_t, nullptr, stream);
 }
 
 extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
@@ -356,6 +384,9 @@ extern "C" int gdm_spline_pairs_aggregate_hip(const float* Y, const int32_t* row
 extern "C" int gdm_spline_direct2_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
                                      const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
                                      float* out, float* out_t, void* stream);
+extern "C" int gdm_spline_direct3_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                     const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                                     float* out, float* out_t, void* out_packed, void* stream);
 
 extern "C" int gdm_spline_direct_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
                                      const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
@@ -368,7 +399,16 @@ extern "C" int gdm_spline_direct2_hip(const float* x, const float* weight, const
                                      const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
                                      float* out, float* out_t, void* stream)
 {
+    return gdm_spline_direct3_hip(x, weight, rowptr, src, attr, root_t, bias, M, Cin, C, kernel_size, relu, out, out_t, nullptr, stream);
+}
+
+extern "C" int gdm_spline_direct3_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                                     const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                                     float* out, float* out_t, void* out_packed, void* stream)
+{
+    unsigned char* out_pk = (unsigned char*)out_packed;
     GDM_CHECK_ARG(x && weight && rowptr && src && attr && (out || out_t), "gdm_spline_direct_hip: NULL pointer");
+    GDM_CHECK_ARG(!out_pk || (C % 128 == 0 && C <= 512), "gdm_spline_direct3_hip: the packed output needs C = 128, 256 or 512");
     GDM_CHECK_ARG(M >= 1 && C >= 1 && kernel_size >= 2 && Cin >= 1 && Cin <= 16, "gdm_spline_direct_hip: bad shape M=%d Cin=%d (<= 16) C=%d ks=%d", M, Cin, C, kernel_size);
     const bool vec = C % 4 == 0 && C <= 512 && 512 % C == 0 && ((uintptr_t)weight & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                      (!root_t || ((uintptr_t)root_t & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
@@ -377,13 +417,13 @@ extern "C" int gdm_spline_direct2_hip(const float* x, const float* weight, const
         const dim3 grid(gdm_cdiv(M, vpb));
         if (relu)
             hipLaunchKernelGGL((spline_direct_vec_kernel<true, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
-                               bias, M, Cin, C, kernel_size, out, out_t);
+                               bias, M, Cin, C, kernel_size, out, out_t, out_pk);
         else
             hipLaunchKernelGGL((spline_direct_vec_kernel<false, 16>), grid, dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t,
-                               bias, M, Cin, C, kernel_size, out, out_t);
+                               bias, M, Cin, C, kernel_size, out, out_t, out_pk);
         return gdm_launch_status("spline_direct_vec_kernel");
     }
-    GDM_CHECK_ARG(out && !out_t, "gdm_spline_direct2_hip: the channel-major output needs C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
+    GDM_CHECK_ARG(out && !out_t && !out_pk, "gdm_spline_direct2_hip: the channel-major / packed outputs need C %% 4 == 0, 512 %% C == 0 and 16-byte aligned buffers");
     if (relu)
         hipLaunchKernelGGL((spline_direct_kernel<true, 16>), dim3(M), dim3(128), 0, (hipStream_t)stream, x, weight, rowptr, src, attr, root_t, bias, Cin, C, kernel_size, out);
     else

@@ -665,6 +665,29 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_m
     return out
 
 
+def pointwise_jobs(xs, wts):
+    """Up to four independent plain per-point layers of equal K and Cout in ONE launch (include/gdm.h gdm_pointwise_jobs_hip):
+    xs[j] f32[B,K,n_j], wts[j] f32[K,Cout] (the weight transposed) -> [f32[B,Cout,n_j]].  Bit-identical to `pointwise([x], wt)` per
+    job (same tile function, same K split); the library refuses jobs whose K splits would differ."""
+    if not (1 <= len(xs) <= 4 and len(xs) == len(wts)):
+        raise ValueError("pointwise_jobs: one to four (x, wt) pairs")
+    B, K = xs[0].shape[0], xs[0].shape[1]
+    Cout = wts[0].shape[1]
+    arr = (_lib.PwJob * len(xs))()
+    keep, outs = [], []
+    for j, (x, wt) in enumerate(zip(xs, wts)):
+        x = _dev(x.reshape(x.shape[0], x.shape[1], -1), torch.float32, "xs[%d]" % j)
+        wt = _dev(wt, torch.float32, "wts[%d]" % j)
+        if x.shape[0] != B or x.shape[1] != K or tuple(wt.shape) != (K, Cout):
+            raise ValueError("pointwise_jobs: job %d has x %s / wt %s, job 0 has B=%d K=%d Cout=%d" % (j, tuple(x.shape), tuple(wt.shape), B, K, Cout))
+        out = torch.empty((B, Cout, x.shape[2]), dtype=torch.float32, device=x.device)
+        arr[j] = _lib.PwJob(x.data_ptr(), wt.data_ptr(), out.data_ptr(), x.shape[2])
+        keep += [x, wt]
+        outs.append(out)
+    check(_lib.lib().gdm_pointwise_jobs_hip(arr, len(xs), B, K, Cout, _stream()), "gdm_pointwise_jobs_hip")
+    return outs
+
+
 def _fold_and_all_reduce(sums, C, group):
     """Partial pairs [G][C][2] + count + G  ->  double[2C+1] = one pair per channel + count, summed over the ranks of `group`."""
     import torch.distributed as dist
@@ -1604,15 +1627,22 @@ def gemm_bf16x3(x, wpk, cout, scale=None, shift=None, act=ACT_NONE, pixel_major=
     return out
 
 
-def gemm_grouped(x_cm, wpk, rowidx, tile_co0, cout_total):
+def spline_packed_buffer(C, M, device, avoid=None):
+    """The zero-bordered operand buffer a SplineConv layer's kernels write for the NEXT layer's grouped GEMM (a [1, C, 1, M] map)."""
+    return _packed_buffer(1, C, 1, M, device, avoid=avoid)
+
+
+def gemm_grouped(x_cm, wpk, rowidx, tile_co0, cout_total, xpk=None):
     """Grouped, gathered GEMM on the split-bf16 MFMA kernel (include/gdm.h gdm_gemm_grouped_hip): x_cm f32[1,Cin,M] (channel-major),
-    wpk = gemm_pack_weight of a [cout_total, Cin] matrix, rowidx i32[R] (R % 256 == 0), tile_co0 i32[R/256] -> Y f32[R,128]."""
+    wpk = gemm_pack_weight of a [cout_total, Cin] matrix, rowidx i32[R] (R % 256 == 0), tile_co0 i32[R/256] -> Y f32[R,128].
+    xpk: the packed operand of x_cm when its producer wrote it (gdm_spline_*3_hip); otherwise one pack launch makes it here."""
     x_cm = _dev(x_cm, torch.float32, "x")
     _, Cin, M = x_cm.shape
     R = rowidx.shape[0]
     L = _lib.lib()
-    xpk = _packed_buffer(1, Cin, 1, M, x_cm.device)
-    check(L.gdm_conv3x3_pack_act_hip(x_cm.data_ptr(), 1, Cin, 1, M, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
+    if xpk is None:
+        xpk = _packed_buffer(1, Cin, 1, M, x_cm.device)
+        check(L.gdm_conv3x3_pack_act_hip(x_cm.data_ptr(), 1, Cin, 1, M, xpk.data_ptr(), _stream()), "gdm_conv3x3_pack_act_hip")
     Y = torch.empty((R, 128), dtype=torch.float32, device=x_cm.device)
     check(L.gdm_gemm_grouped_hip(xpk.data_ptr(), wpk.data_ptr(), rowidx.data_ptr(), tile_co0.data_ptr(), R, M, Cin, cout_total,
                                  Y.data_ptr(), _stream()), "gdm_gemm_grouped_hip")

@@ -90,26 +90,36 @@ class SplineConv(nn.Module):
     def forward_direct_cm(self, x, rowptr, src, attr, relu):
         """First layer (cin <= 16), result CHANNEL-major f32[1, cout, M]: what the next layer's grouped GEMM / root product and the
         final linear read in place (no transposing copy)."""
+        return self.forward_direct_cm_packed(x, rowptr, src, attr, relu, False)[0]
+
+    def forward_direct_cm_packed(self, x, rowptr, src, attr, relu, want_packed):
+        """... and, want_packed, ALSO as the packed split-bf16 operand of the next layer's grouped GEMM (the kernel writes it itself: no
+        pack launch between the layers).  Returns (out_t, packed buffer or None)."""
         M = x.shape[0]
         out_t = torch.empty((1, self.cout, M), dtype=torch.float32, device=x.device)
+        pk = ops.spline_packed_buffer(self.cout, M, x.device) if want_packed and self.cout % 128 == 0 and self.cout <= 512 else None
         xc = x.contiguous()
-        check(_lib.lib().gdm_spline_direct2_hip(xc.data_ptr(), self.weight.data_ptr(), rowptr.data_ptr(), src.data_ptr(), attr.data_ptr(),
+        check(_lib.lib().gdm_spline_direct3_hip(xc.data_ptr(), self.weight.data_ptr(), rowptr.data_ptr(), src.data_ptr(), attr.data_ptr(),
                                                 self._root_t().data_ptr(), self.bias.data_ptr(), M, self.cin, self.cout, KERNEL_SIZE, int(relu),
-                                                None, out_t.data_ptr(), ops._stream()), "gdm_spline_direct2_hip")
-        return out_t
+                                                None, out_t.data_ptr(), pk.data_ptr() if pk is not None else None, ops._stream()),
+              "gdm_spline_direct3_hip")
+        return out_t, pk
 
-    def forward_grouped_cm(self, xt, rowptr, pairs, relu):
-        """128 -> 128 layer on the edge-grouped GEMM, channel-major in (xt f32[1, cin, M]) and out (f32[1, cout, M])."""
+    def forward_grouped_cm(self, xt, rowptr, pairs, relu, xpk=None, want_packed=False):
+        """128 -> 128 layer on the edge-grouped GEMM, channel-major in (xt f32[1, cin, M]) and out (f32[1, cout, M]).  xpk: xt's packed
+        operand when the previous layer wrote it; want_packed: this layer's result also as the next layer's -> (out_t, packed or None)."""
         M = xt.shape[2]
         nk = KERNEL_SIZE ** 3
         wpk, _ = cached_gemm_weight(self, "dense", lambda: self.weight.permute(0, 2, 1).reshape(nk * self.cout, self.cin), (self.weight,))
-        Y = ops.gemm_grouped(xt, wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout)
+        Y = ops.gemm_grouped(xt, wpk, pairs["rowidx"], pairs["tile_co0"], nk * self.cout, xpk=xpk)
         root = ops.pointwise([xt], self._root_t(), point_major=True)                       # [1, M, cout] = x @ W_root^T
         out_t = torch.empty((1, self.cout, M), dtype=torch.float32, device=xt.device)
-        check(_lib.lib().gdm_spline_pairs_aggregate2_hip(Y.data_ptr(), rowptr.data_ptr(), pairs["pos"].data_ptr(), pairs["basis"].data_ptr(),
+        pk = ops.spline_packed_buffer(self.cout, M, xt.device, avoid=xpk) if want_packed and self.cout % 128 == 0 and self.cout <= 512 else None
+        check(_lib.lib().gdm_spline_pairs_aggregate3_hip(Y.data_ptr(), rowptr.data_ptr(), pairs["pos"].data_ptr(), pairs["basis"].data_ptr(),
                                                          root.data_ptr(), self.bias.data_ptr(), M, self.cout, int(relu), None,
-                                                         out_t.data_ptr(), ops._stream()), "gdm_spline_pairs_aggregate2_hip")
-        return out_t
+                                                         out_t.data_ptr(), pk.data_ptr() if pk is not None else None, ops._stream()),
+              "gdm_spline_pairs_aggregate3_hip")
+        return out_t, pk
 
     def forward(self, x, rowptr, src, attr, relu=False, pairs=None):
         M = x.shape[0]
@@ -341,9 +351,13 @@ class SplineCNN_Mesh(nn.Module):
             self.__dict__["_gdm_x0_t"] = cache
         segs = [cache[1]]
         convs = list(self.mesh_convs)
-        segs.append(convs[0].forward_direct_cm(x0, rowptr, src, attr, True))
-        for conv in convs[1:]:
-            segs.append(conv.forward_grouped_cm(segs[-1], rowptr, self._pairs, True))
+        # each layer's kernel also writes the packed operand of the NEXT layer's grouped GEMM (settings.USE_PACKED_PRODUCERS)
+        packed = settings.USE_PACKED_PRODUCERS
+        out_t, pk = convs[0].forward_direct_cm_packed(x0, rowptr, src, attr, True, packed and len(convs) > 1)
+        segs.append(out_t)
+        for li, conv in enumerate(convs[1:]):
+            out_t, pk = conv.forward_grouped_cm(segs[-1], rowptr, self._pairs, True, xpk=pk, want_packed=packed and li + 2 < len(convs))
+            segs.append(out_t)
         w = self.mesh_final.weight
         key = (w._version, w.data_ptr())
         cache = self.mesh_final.__dict__.get("_gdm_wt")

@@ -210,6 +210,15 @@ int gdm_spline_direct2_hip(const float* x, const float* weight, const int32_t* r
                            float* out, float* out_t, void* stream);
 int gdm_spline_pairs_aggregate2_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
                                     const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t, void* stream);
+/* ... and with an optional THIRD output out_packed: the result as the split-bf16 operand planes of the next layer's grouped GEMM
+ * (gdm_conv3x3_act_bytes(1, C, 1, M) bytes, the layout gdm_conv3x3_pack_act_hip(x_cm, 1, C, 1, M) writes; zero border in place, C = 128,
+ * 256 or 512): the pack launch between two SplineConv layers (SplineCNN.py:238-239) is then not needed. */
+int gdm_spline_direct3_hip(const float* x, const float* weight, const int32_t* rowptr, const int32_t* src, const float* attr,
+                           const float* root_t, const float* bias, int M, int Cin, int C, int kernel_size, int relu,
+                           float* out, float* out_t, void* out_packed, void* stream);
+int gdm_spline_pairs_aggregate3_hip(const float* Y, const int32_t* rowptr, const int32_t* pos, const float* basis,
+                                    const float* root, const float* bias, int M, int C, int relu, float* out, float* out_t,
+                                    void* out_packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=True, NCHW fp32 (models/cnn/pspnet.py:26-29,38).
@@ -498,6 +507,17 @@ typedef struct {
 } gdm_pw_seg;
 int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
                       int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
+/* Up to four independent plain layers out_j f32[B,Cout,n_j] = W_j^T . x_j (x_j f32[B,K,n_j], wt_j f32[K,Cout]; no scale / shift /
+ * activation) of equal K >= 32 and Cout in ONE launch: the four prior products of the pyramid-pooling module
+ * (/root/reference/models/cnn/pspnet.py:17-31, `stage(feats)` of the 1 / 2 / 3 / 6-bin pools folded with the bottleneck's slices).
+ * Bit-identical to njobs calls of gdm_pointwise_hip; jobs that would take different K splits alone are refused (-> error). */
+typedef struct {
+    const float* x;
+    const float* wt;
+    float* out;
+    int32_t n;
+} gdm_pw_job;
+int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, int K, int Cout, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * The ResNet stem in one launch (inference): conv 7x7 / stride 2 / pad 3 (3 -> 64, no bias) + scale / shift (folded BatchNorm) +

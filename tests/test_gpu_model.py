@@ -124,6 +124,30 @@ def test_mesh_branch_vs_oracle(golden_model):
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
 
 
+def test_mesh_branch_packed_producers_equal_the_pack_launches_bit_for_bit(golden_model):
+    """The SplineConv kernels write the next layer's packed split-bf16 operand themselves (gdm_spline_direct3_hip /
+    gdm_spline_pairs_aggregate3_hip) == the separate pack launch over their fp32 result: same bytes, so the same mesh descriptors."""
+    from geometric_aware_dense_matching_amd import ops
+    model, _ = golden_model
+    saved = settings.USE_PACKED_PRODUCERS
+    try:
+        with torch.no_grad():
+            settings.USE_PACKED_PRODUCERS = True
+            a = model.model_emb().clone()
+            settings.USE_PACKED_PRODUCERS = False
+            b = model.model_emb().clone()
+            # the operand bytes themselves, first layer
+            emb = model.model_emb
+            rowptr, src, attr = emb._ensure_graph()
+            out_t, pk = list(emb.mesh_convs)[0].forward_direct_cm_packed(emb.mesh_graph_x, rowptr, src, attr, True, True)
+            mine = pk.clone()
+            ref = ops.conv3x3_pack_act(out_t.unsqueeze(2).contiguous())          # [1, C, 1, M]
+    finally:
+        settings.USE_PACKED_PRODUCERS = saved
+    assert torch.equal(a, b)
+    assert torch.equal(ref.buf, mine)
+
+
 def test_training_losses_vs_reference_golden(golden_model):
     model, _ = golden_model
     g = np.load(os.path.join(G, "losses.npz"))

@@ -758,6 +758,31 @@ def test_pointwise_rejects_bad_arguments(ops):
         ops.pointwise([x.cpu()], torch.randn(8, 4))                              # no CPU path
 
 
+@pytest.mark.parametrize("B,K,Cout,ns", [(16, 512, 1024, (1, 4, 9, 36)), (2, 512, 1024, (1, 4, 9, 36)), (3, 64, 40, (5, 64)), (1, 128, 16, (7,))])
+def test_pointwise_jobs_equal_separate_launches_bit_for_bit(ops, B, K, Cout, ns):
+    """gdm_pointwise_jobs_hip (the four prior products of the pyramid-pooling module, pspnet.py:17-31, in one launch) == one
+    gdm_pointwise_hip launch per job, bit for bit (same tile function, same K split), and == the fp64 product at fp32 accuracy."""
+    g = torch.Generator(device="cpu").manual_seed(K + Cout + len(ns))
+    xs = [torch.randn(B, K, n, generator=g).cuda() for n in ns]
+    wts = [(torch.randn(K, Cout, generator=g) / K ** 0.5).cuda() for _ in ns]
+    got = ops.pointwise_jobs(xs, wts)
+    for x, wt, y in zip(xs, wts, got):
+        assert torch.equal(y, ops.pointwise([x], wt))
+        want = torch.einsum("kc,bkn->bcn", wt.double(), x.double())
+        assert (y.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+
+
+def test_pointwise_jobs_reject_mixed_k_splits_and_shapes(ops):
+    x = torch.randn(2, 64, 8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.pointwise_jobs([x, torch.randn(2, 32, 8, device="cuda")], [torch.randn(64, 16, device="cuda"), torch.randn(32, 16, device="cuda")])
+    big = torch.randn(4, 512, 16384, device="cuda")                              # alone: no K split; the 4-point job alone: eight parts
+    small = torch.randn(4, 512, 1, device="cuda")
+    w = torch.randn(512, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.pointwise_jobs([small, big], [w, w])
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 100, 70), (3, 64, 128), (1, 7, 9)])
 def test_stem_kernel_vs_torch_fp64(ops, B, H, W):
     """gdm_stem_hip == maxpool3x3/2/p1(relu(bn(conv7x7/2/p3(x)))) (extractors.py:112-116,181-185) in fp64 torch: split-bf16 products
