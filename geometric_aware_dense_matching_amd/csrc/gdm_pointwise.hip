@@ -591,56 +591,67 @@ extern "C" int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, 
 {
     GDM_CHECK_ARG(jobs && njobs >= 1 && njobs <= 4, "gdm_pointwise_jobs_hip: njobs=%d not in [1,4]", njobs);
     GDM_CHECK_ARG(B >= 1 && K >= 32 && Cout >= 1 && gdm_cdiv(Cout, 16) <= 65535, "gdm_pointwise_jobs_hip: bad shape B=%d K=%d Cout=%d", B, K, Cout);
-    PwArgs a[4];
-    int ends[4];
-    int vecmask = 0;
-    long tiles = 0;
-    for (int j = 0; j < 4; ++j) {
-        const gdm_pw_job& jb = jobs[j < njobs ? j : njobs - 1];
-        if (j < njobs) {
-            GDM_CHECK_ARG(jb.x && jb.wt && jb.out && jb.n >= 1, "gdm_pointwise_jobs_hip: job %d: NULL pointer or n=%d", j, jb.n);
-            GDM_CHECK_ARG(((uintptr_t)jb.out & 15) == 0, "gdm_pointwise_jobs_hip: job %d: out must be 16-byte aligned", j);
-        }
-        for (int s = 0; s < MAXSEG; ++s) a[j].seg[s] = PwSegDev{nullptr, nullptr, 0, 0};
-        a[j].seg[0] = PwSegDev{jb.x, nullptr, K, jb.n};
-        a[j].nseg = 1;
-        a[j].wt = jb.wt;
-        a[j].scale = nullptr;
-        a[j].shift = nullptr;
-        a[j].out = jb.out;
-        a[j].n = jb.n;
-        a[j].Cout = Cout;
-        a[j].outC = Cout;
-        a[j].out_c0 = 0;
-        a[j].point_major = 0;
-        a[j].act = 0;
-        a[j].slope = 0.f;
-        a[j].K = K;
-        a[j].total = (long)B * jb.n;
-        if (j < njobs) {
-            tiles += (a[j].total + PT - 1) / PT;
-            if (jb.n % 4 == 0 && ((uintptr_t)jb.x & 15) == 0 && !getenv("GDM_PW_NOVEC")) vecmask |= 1 << j;
-        }
-        ends[j] = (int)tiles;                                        // jobs past njobs own no blocks
-    }
-    GDM_CHECK_ARG(tiles <= 0x7fffffffL, "gdm_pointwise_jobs_hip: grid too large");
-    // the K split of gdm_pointwise_hip, chosen PER JOB there: the jobs launched together must agree with their separate launches bit for
-    // bit, so the split is the smallest any of them would take alone (a smaller job never takes fewer parts than a larger one)
-    int ks = 8;
+    // the K split of gdm_pointwise_hip is chosen PER JOB there (from its own grid size); a job launched here must agree with its separate
+    // launch bit for bit, so jobs are launched together only with the jobs that take the same split: one launch per distinct split
+    // (the pyramid-pooling products at batch 16: all four take eight parts -> one launch; at batch 32 the 36-bin job takes four -> two)
+    int kjob[4] = {0, 0, 0, 0};
     for (int j = 0; j < njobs; ++j) {
-        const long tj = (a[j].total + PT - 1) / PT;
+        const gdm_pw_job& jb = jobs[j];
+        GDM_CHECK_ARG(jb.x && jb.wt && jb.out && jb.n >= 1, "gdm_pointwise_jobs_hip: job %d: NULL pointer or n=%d", j, jb.n);
+        GDM_CHECK_ARG(((uintptr_t)jb.out & 15) == 0, "gdm_pointwise_jobs_hip: job %d: out must be 16-byte aligned", j);
+        const long tj = ((long)B * jb.n + PT - 1) / PT;
         int kj = 1;
         while (kj < 8 && K / (2 * kj) >= 16 && tj * gdm_cdiv(Cout, 16) * kj < 4096) kj *= 2;
-        GDM_CHECK_ARG(j == 0 || kj == ks, "gdm_pointwise_jobs_hip: job %d would split K into %d parts alone, job 0 into %d: launch them apart", j, kj, ks);
-        ks = kj;
+        kjob[j] = kj;
     }
-    const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, 16));
     hipStream_t st = (hipStream_t)stream;
+    for (int ks = 1; ks <= 8; ks *= 2) {
+        PwArgs a[4];
+        int ends[4];
+        int vecmask = 0, m = 0;
+        long tiles = 0;
+        const gdm_pw_job* last = nullptr;
+        for (int j = 0; j < njobs; ++j) {
+            if (kjob[j] != ks) continue;
+            const gdm_pw_job& jb = jobs[j];
+            last = &jb;
+            for (int sgi = 0; sgi < MAXSEG; ++sgi) a[m].seg[sgi] = PwSegDev{nullptr, nullptr, 0, 0};
+            a[m].seg[0] = PwSegDev{jb.x, nullptr, K, jb.n};
+            a[m].nseg = 1;
+            a[m].wt = jb.wt;
+            a[m].scale = nullptr;
+            a[m].shift = nullptr;
+            a[m].out = jb.out;
+            a[m].n = jb.n;
+            a[m].Cout = Cout;
+            a[m].outC = Cout;
+            a[m].out_c0 = 0;
+            a[m].point_major = 0;
+            a[m].act = 0;
+            a[m].slope = 0.f;
+            a[m].K = K;
+            a[m].total = (long)B * jb.n;
+            tiles += (a[m].total + PT - 1) / PT;
+            if (jb.n % 4 == 0 && ((uintptr_t)jb.x & 15) == 0 && !getenv("GDM_PW_NOVEC")) vecmask |= 1 << m;
+            ends[m] = (int)tiles;
+            ++m;
+        }
+        if (m == 0) continue;
+        for (int q = m; q < 4; ++q) {                                  // unused slots: valid pointers, no blocks
+            a[q] = a[m - 1];
+            ends[q] = (int)tiles;
+        }
+        (void)last;
+        GDM_CHECK_ARG(tiles <= 0x7fffffffL, "gdm_pointwise_jobs_hip: grid too large");
+        const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, 16));
 #define GDM_PWJ(KSV) hipLaunchKernelGGL((pointwise_mfma_jobs_kernel<KSV>), grid, dim3(KSV * 64), 0, st, a[0], a[1], a[2], a[3], ends[0], ends[1], ends[2], vecmask)
-    if (ks == 1) GDM_PWJ(1);
-    else if (ks == 2) GDM_PWJ(2);
-    else if (ks == 4) GDM_PWJ(4);
-    else GDM_PWJ(8);
+        if (ks == 1) GDM_PWJ(1);
+        else if (ks == 2) GDM_PWJ(2);
+        else if (ks == 4) GDM_PWJ(4);
+        else GDM_PWJ(8);
 #undef GDM_PWJ
-    return gdm_launch_status("pointwise_mfma_jobs_kernel");
+        const int rc = gdm_launch_status("pointwise_mfma_jobs_kernel");
+        if (rc) return rc;
+    }
+    return 0;
 }

@@ -668,7 +668,7 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_m
 def pointwise_jobs(xs, wts):
     """Up to four independent plain per-point layers of equal K and Cout in ONE launch (include/gdm.h gdm_pointwise_jobs_hip):
     xs[j] f32[B,K,n_j], wts[j] f32[K,Cout] (the weight transposed) -> [f32[B,Cout,n_j]].  Bit-identical to `pointwise([x], wt)` per
-    job (same tile function, same K split); the library refuses jobs whose K splits would differ."""
+    job (same tile function, same K split); jobs whose K splits would differ alone go in one launch per distinct split."""
     if not (1 <= len(xs) <= 4 and len(xs) == len(wts)):
         raise ValueError("pointwise_jobs: one to four (x, wt) pairs")
     B, K = xs[0].shape[0], xs[0].shape[1]

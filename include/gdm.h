@@ -510,7 +510,8 @@ int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const f
 /* Up to four independent plain layers out_j f32[B,Cout,n_j] = W_j^T . x_j (x_j f32[B,K,n_j], wt_j f32[K,Cout]; no scale / shift /
  * activation) of equal K >= 32 and Cout in ONE launch: the four prior products of the pyramid-pooling module
  * (/root/reference/models/cnn/pspnet.py:17-31, `stage(feats)` of the 1 / 2 / 3 / 6-bin pools folded with the bottleneck's slices).
- * Bit-identical to njobs calls of gdm_pointwise_hip; jobs that would take different K splits alone are refused (-> error). */
+ * Bit-identical to njobs calls of gdm_pointwise_hip: jobs that would take different K splits alone (gdm_pointwise_hip picks the split
+ * from a job's own grid size) are launched apart, one launch per distinct split. */
 typedef struct {
     const float* x;
     const float* wt;
