@@ -190,6 +190,32 @@ def test_headline_batch16_rows_equal_batch2_rows(headline_model, c2_run):
         assert (res["best_sim"][b].cpu() - wv).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("B", [1, 3, 32])
+def test_headline_shape_at_other_batch_sizes(headline_model, c2_run, B):
+    """Launch-shape decisions that depend on the batch (K splits of the per-point layers, grouped launches, tile shapes, grid limits):
+    the step at batch 1 / 3 / 32 runs, and the crops it shares with the batch-2 run (synthetic.make_batch draws crop i from (seed, i))
+    give that run's results at the tolerance of test_headline_batch16_rows_equal_batch2_rows.  Batch 32 is north_star's end-to-end
+    target batch and bench.py's `b32` extra."""
+    from geometric_aware_dense_matching_amd import matching
+    model, _ = headline_model
+    _, d2, ep2, _, res2 = c2_run
+    batch = synthetic.make_batch(seed=21, batch=B, n_points=N2)
+    d = _with_pyramid(_dev_inputs(batch))
+    n = min(B, 2)
+    for k, v in d2.items():
+        assert torch.equal(d[k][:n], v[:n]), k
+    with torch.no_grad():
+        ep = model(dict(d))
+        res = matching.match_frames(ep)
+    assert ep["rgbd"].shape == (B, 128, N2) and torch.isfinite(ep["rgbd"]).all() and torch.isfinite(ep["seg"]).all()
+    scale = ep2["rgbd"].abs().max().item()
+    assert (ep["rgbd"][:n] - ep2["rgbd"][:n]).abs().max().item() < 5e-5 * scale
+    assert (ep["seg"][:n] - ep2["seg"][:n]).abs().max().item() < 1e-4 * max(1.0, ep2["seg"].abs().max().item())
+    assert (res["best_sim"][:n] - res2["best_sim"][:n]).abs().max().item() < 1e-5
+    assert (res["best_idx"][:n] == res2["best_idx"][:n]).float().mean().item() > 0.9995
+    assert int(res["best_idx"].max()) < M2 and int(res["best_idx"].min()) >= 0
+
+
 # --------------------------------------------------------------------------------------------- goldens read directly
 def test_knn_duplicate_points_vs_reference_golden():
     """knn_dup.npz = the compiled reference nanoflann on a cloud with exact duplicates (np.pad 'wrap').  HIP kNN: bit-equal
