@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
                 v = lrelu(fmaf(v, sc, sh), slope);
                 if (a.w2t) fx1[p][j][k] = v;
                 else fcat[p][H + j][k] = v;
+#if defined(GDM_LFA_EXP) && (GDM_LFA_EXP & 1)
+                fcat[p][j][k] = (a.feat + (long)b * H * n)[(long)nidx[p][k] * H + j];   // development: the access pattern of a point-major feature array (wrong values)
+#else
                 fcat[p][j][k] = frow[nidx[p][k]];
+#endif
             }
         }
     }
@@ -355,7 +359,11 @@ __global__ __launch_bounds__(256) void lfa_stage_mfma_kernel(const LfaArgs a)
                 v = lrelu(fmaf(v, sc, sh), slope);
                 if (a.w2t) fx1[p][j][k] = v;
                 else fcat[p][H + j][k] = v;
+#if defined(GDM_LFA_EXP) && (GDM_LFA_EXP & 1)
+                fcat[p][j][k] = (a.feat + (long)b * H * n)[(long)nidx[p][k] * H + j];   // development: the access pattern of a point-major feature array (wrong values)
+#else
                 fcat[p][j][k] = frow[nidx[p][k]];
+#endif
             }
         }
     }
