@@ -53,6 +53,7 @@ SIGNATURES = {
     "gdm_match_rows_bytes": (_sz, [_i]),
     "gdm_match_partial_bytes": (_sz, [_i, _i]),
     "gdm_match_pack_hip": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_match_pack2_hip": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "gdm_match_packed_hip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdm_seg_mask_hip": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gdm_upsample_bilinear_hip": (_i, [_vp, ctypes.c_long, _i, _i, _i, _i, _vp, _vp]),

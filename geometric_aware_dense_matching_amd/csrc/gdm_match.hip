@@ -45,13 +45,11 @@ constexpr int TILE_BYTES = MT_COLS * ROW_BYTES;   // 32 KiB
 // pack: [R, 128, n] -> R*n rows
 // ------------------------------------------------------------------------------------------
 
+// one block: 64 points (from p0) of row set r
 template <int PREC>
-__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int n, unsigned char* __restrict__ out)
+__device__ __forceinline__ void pack_rows_tile(const float* __restrict__ x, int n, unsigned char* __restrict__ out, const int r, const int p0,
+                                               float (*t)[65], float (*part)[64])
 {
-    __shared__ float t[D][65];
-    __shared__ float part[4][64];
-    const int r = blockIdx.y;
-    const int p0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int p = min(p0 + lane, n - 1);
@@ -88,6 +86,31 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             *reinterpret_cast<float4*>(row + ch * 32) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(row + ch * 32 + 16) = make_float4(v[4], v[5], v[6], v[7]);
         }
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int n, unsigned char* __restrict__ out)
+{
+    __shared__ float t[D][65];
+    __shared__ float part[4][64];
+    pack_rows_tile<PREC>(x, n, out, blockIdx.y, blockIdx.x * 64, t, part);
+}
+
+// two independent packs in one launch (the scene descriptors [R1, 128, n1] and the model descriptors [R2, 128, n2] of one step):
+// blockIdx.y < R1 walks the first, the rest the second; the same tile function, so the same bytes as two launches
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_rows2_kernel(const float* __restrict__ x1, int R1, int n1, unsigned char* __restrict__ out1,
+                                                         const float* __restrict__ x2, int n2, unsigned char* __restrict__ out2)
+{
+    __shared__ float t[D][65];
+    __shared__ float part[4][64];
+    const int p0 = blockIdx.x * 64;
+    const int y = blockIdx.y;
+    if (y < R1) {
+        if (p0 < n1) pack_rows_tile<PREC>(x1, n1, out1, y, p0, t, part);
+    } else {
+        if (p0 < n2) pack_rows_tile<PREC>(x2, n2, out2, y - R1, p0, t, part);
     }
 }
 
@@ -999,6 +1022,23 @@ extern "C" int gdm_match_pack_hip(const float* x, int R, int Dd, int n, int prec
     return gdm_launch_status("pack_rows_kernel");
 }
 
+extern "C" int gdm_match_pack2_hip(const float* x1, int R1, int n1, void* rows1, const float* x2, int R2, int n2, void* rows2,
+                                   int Dd, int precision, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    GDM_CHECK_ARG(x1 && rows1 && x2 && rows2, "gdm_match_pack2_hip: NULL pointer");
+    GDM_CHECK_ARG(Dd == D, "gdm_match_pack2_hip: D=%d, only D=128 is built", Dd);
+    GDM_CHECK_ARG(R1 >= 1 && R2 >= 1 && R1 + R2 <= 65535 && n1 >= 1 && n2 >= 1, "gdm_match_pack2_hip: bad shape R=%d+%d n=%d,%d", R1, R2, n1, n2);
+    GDM_CHECK_ARG(precision == GDM_MATCH_BF16X3 || precision == GDM_MATCH_F32, "gdm_match_pack2_hip: precision=%d", precision);
+    GDM_CHECK_ARG((((uintptr_t)rows1 | (uintptr_t)rows2) & 15) == 0, "gdm_match_pack2_hip: rows must be 16-byte aligned");
+    dim3 grid(gdm_cdiv(n1 > n2 ? n1 : n2, 64), R1 + R2);
+    if (precision == GDM_MATCH_BF16X3)
+        hipLaunchKernelGGL(pack_rows2_kernel<GDM_MATCH_BF16X3>, grid, dim3(256), 0, stream, x1, R1, n1, (unsigned char*)rows1, x2, n2, (unsigned char*)rows2);
+    else
+        hipLaunchKernelGGL(pack_rows2_kernel<GDM_MATCH_F32>, grid, dim3(256), 0, stream, x1, R1, n1, (unsigned char*)rows1, x2, n2, (unsigned char*)rows2);
+    return gdm_launch_status("pack_rows2_kernel");
+}
+
 extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_rows, int R, int M, int precision,
                                     int32_t* best_idx, float* best_sim, float* sim,
                                     void* partial, size_t partial_bytes, void* stream_)
@@ -1102,9 +1142,7 @@ extern "C" int gdm_match_hip(const float* scene, const float* model, int B, int 
     unsigned char* apk = ws;
     unsigned char* bpk = apk + gdm_match_rows_bytes(B * N);
     unsigned char* part = bpk + gdm_match_rows_bytes(M);
-    int rc = gdm_match_pack_hip(scene, B, Dd, N, precision, apk, stream);
-    if (rc) return rc;
-    rc = gdm_match_pack_hip(model, 1, Dd, M, precision, bpk, stream);
+    int rc = gdm_match_pack2_hip(scene, B, N, apk, model, 1, M, bpk, Dd, precision, stream);
     if (rc) return rc;
     return gdm_match_packed_hip(apk, bpk, B * N, M, precision, best_idx, best_sim, sim, part, gdm_match_partial_bytes(B, N), stream);
 }

@@ -37,10 +37,11 @@ def match_tail(end_points, B, N, M, precision=ops.MATCH_BF16X3):
     from . import settings
     seg, rgbd, mesh = end_points["seg"], end_points["rgbd"], end_points["mesh"]
     forked = settings.USE_SIDE_STREAMS and seg.is_cuda and not torch.is_grad_enabled()
-    srows = ops.match_pack(rgbd, precision)
     mrows = end_points.get("mesh_rows") if precision == ops.MATCH_BF16X3 else None
     if mrows is None:
-        mrows = ops.match_pack(mesh[0] if mesh.dim() == 3 else mesh, precision)
+        srows, mrows = ops.match_pack2(rgbd, mesh[0] if mesh.dim() == 3 else mesh, precision)      # both packs, one launch
+    else:
+        srows = ops.match_pack(rgbd, precision)
     pending = end_points.pop("_seg_fork", None)            # GeoMatch.forward(defer_seg=True): `seg` is still being formed on side stream 0
     if forked:
         with ops.fork(seg.device, 0) as f:                   # side stream 0: behind the segmentation layers, if they are pending there

@@ -1752,6 +1752,23 @@ def match_pack(x, precision=MATCH_BF16X3, out=None):
     return out
 
 
+def match_pack2(x1, x2, precision=MATCH_BF16X3):
+    """match_pack(x1), match_pack(x2) in one launch (include/gdm.h gdm_match_pack2_hip): the scene and the model descriptors of a step."""
+    x1 = _dev(x1, torch.float32, "x1")
+    x2 = _dev(x2, torch.float32, "x2")
+    x1 = x1.unsqueeze(0) if x1.dim() == 2 else x1
+    x2 = x2.unsqueeze(0) if x2.dim() == 2 else x2
+    (R1, D, n1), (R2, D2, n2) = x1.shape, x2.shape
+    if D != D2:
+        raise ValueError("match_pack2: %d vs %d channels" % (D, D2))
+    L = _lib.lib()
+    o1 = torch.empty((L.gdm_match_rows_bytes(R1 * n1),), dtype=torch.uint8, device=x1.device)
+    o2 = torch.empty((L.gdm_match_rows_bytes(R2 * n2),), dtype=torch.uint8, device=x1.device)
+    check(L.gdm_match_pack2_hip(x1.data_ptr(), R1, n1, o1.data_ptr(), x2.data_ptr(), R2, n2, o2.data_ptr(), D, precision, _stream()),
+          "gdm_match_pack2_hip")
+    return o1, o2
+
+
 def match_packed(scene_rows, model_rows, B, N, M, precision=MATCH_BF16X3, return_sim=False, sim_out=None):
     """Stage 2 of match on packed rows: the MFMA similarity + arg-max kernel (+ split merge)."""
     L = _lib.lib()

@@ -167,6 +167,10 @@ int gdm_match_hip(const float* scene, const float* model, int B, int D, int N, i
 size_t gdm_match_rows_bytes(int rows);
 size_t gdm_match_partial_bytes(int B, int N);
 int gdm_match_pack_hip(const float* x, int R, int D, int n, int precision, void* rows, void* stream);
+/* two packs in one launch (the scene and the model descriptors of one step; evaluator.py:80-81 normalises both): the same bytes as
+ * gdm_match_pack_hip(x1, R1, D, n1, ..., rows1) + gdm_match_pack_hip(x2, R2, D, n2, ..., rows2) */
+int gdm_match_pack2_hip(const float* x1, int R1, int n1, void* rows1, const float* x2, int R2, int n2, void* rows2,
+                        int D, int precision, void* stream);
 int gdm_match_packed_hip(const void* scene_rows, const void* model_rows, int R /* B*N */, int M, int precision,
                          int32_t* best_idx, float* best_sim, float* sim,
                          void* partial, size_t partial_bytes, void* stream);

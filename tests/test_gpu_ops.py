@@ -772,6 +772,18 @@ def test_pointwise_jobs_equal_separate_launches_bit_for_bit(ops, B, K, Cout, ns)
         assert (y.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("prec", ["MATCH_BF16X3", "MATCH_F32"])
+@pytest.mark.parametrize("R1,n1,n2", [(16, 2048, 8192), (3, 100, 37), (1, 4096, 64)])
+def test_match_pack2_equals_two_pack_launches(ops, prec, R1, n1, n2):
+    """gdm_match_pack2_hip (scene + model descriptor rows of one step in one launch, evaluator.py:80-81) writes the bytes of two
+    gdm_match_pack_hip launches."""
+    g = torch.Generator(device="cpu").manual_seed(R1 * 7 + n2)
+    a, b = torch.randn(R1, 128, n1, generator=g).cuda(), torch.randn(128, n2, generator=g).cuda()
+    p = getattr(ops, prec)
+    o1, o2 = ops.match_pack2(a, b, p)
+    assert torch.equal(o1, ops.match_pack(a, p)) and torch.equal(o2, ops.match_pack(b, p))
+
+
 def test_pointwise_jobs_mixed_k_splits_and_bad_shapes(ops):
     x = torch.randn(2, 64, 8, device="cuda")
     with pytest.raises(ValueError):
