@@ -526,13 +526,17 @@ struct RangeTable {
     int B;
 };
 
-__host__ __device__ inline int range_floats(int W, int H) { return 2 * W + 2 * H + 4; }
+constexpr int KG_ROWS = 16;
+__host__ __device__ inline int range_chunks(int H) { return (H + KG_ROWS - 1) / KG_ROWS; }
+// [key(-lo) | key(hi)] per column, the same per row, then two flag words PER BLOCK of the table's kernel (a block = 16 rows)
+__host__ __device__ inline int range_floats(int W, int H) { return 2 * W + 2 * H + 2 * range_chunks(H); }
 
 // Ratio ranges of every pixel column (x/z) and row (y/z) over the valid pixels (z > 0) of a crop.  The table is stored as ordered
-// unsigned keys so that every entry is a MAX reduction from an all-zero buffer (hipMemsetAsync): [key(-lo) | key(hi)] per column,
-// then per row, then two flag words: bad = a point with z <= 0 that is not the origin, or a non-finite coordinate (no pruning for
-// this crop); hole = a point at the origin.  One block per (entry, crop, 16 rows): rows are reduced inside the block, columns with
-// one atomicMax per column and block.
+// unsigned keys (0 = nothing recorded): [key(-lo) | key(hi)] per column, then per row, then two flag words per block: bad = a point
+// with z <= 0 that is not the origin, or a non-finite coordinate (no pruning for this crop); hole = a point at the origin.  One
+// block per (entry, crop, 16 rows): it reduces ITS 16 rows (and their flags), and -- over all H rows -- ITS slice of the columns
+// (W / blocks-per-crop of them), so every word of the table is written exactly once by plain stores: no zero fill in front of
+// the kernel, no atomics (a max is exact in any order: the same table the atomicMax form made).
 __device__ __forceinline__ unsigned ord_key(float v)
 {
     const unsigned u = (unsigned)__float_as_int(v);
@@ -544,10 +548,9 @@ __device__ __forceinline__ float ord_val(unsigned k)           // inverse; key 0
     return __int_as_float((int)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k));
 }
 
-constexpr int KG_ROWS = 16;
-
 __global__ __launch_bounds__(256) void knn_grid_ranges_kernel(const RangeTable tab)
 {
+    __shared__ float snlo[16][17], shi[16][17];
     int blk = blockIdx.x, ei = 0;
     while (ei + 1 < tab.n && blk >= tab.e[ei].nblocks) { blk -= tab.e[ei].nblocks; ++ei; }
     const RangeEntry& e = tab.e[ei];
@@ -583,24 +586,47 @@ __global__ __launch_bounds__(256) void knn_grid_ranges_kernel(const RangeTable t
             out[2 * W + H + v] = isinf(hi) ? 0u : ord_key(hi);
         }
     }
-    // columns: partial over this block's rows
-    for (int u = tid; u < W; u += 256) {
-        float nlo = -INFINITY, hi = -INFINITY;
-        for (int v = v0; v < min(v0 + KG_ROWS, H); ++v) {
-            const float* p = sup + ((long long)v * W + u) * 3;
-            const float x = p[0], z = p[2];
-            if (z > 0.f && isfinite(x) && isfinite(z)) {
-                const float a = x / z;
-                nlo = fmaxf(nlo, -a);
-                hi = fmaxf(hi, a);
-            }
+    // this block's flag words
+    {
+        const int bad = __syncthreads_or((int)(flags & 1u)), hole = __syncthreads_or((int)(flags & 2u));
+        if (tid == 0) {
+            const int c = v0 / KG_ROWS;
+            out[2 * W + 2 * H + 2 * c] = bad ? 1u : 0u;
+            out[2 * W + 2 * H + 2 * c + 1] = hole ? 1u : 0u;
         }
-        if (!isinf(nlo)) atomicMax(out + u, ord_key(nlo));
-        if (!isinf(hi)) atomicMax(out + W + u, ord_key(hi));
     }
-    if (__ballot(flags != 0u)) {
-        if (flags & 1u) atomicOr(out + 2 * W + 2 * H, 1u);
-        if (flags & 2u) atomicOr(out + 2 * W + 2 * H + 1, 1u);
+    // this block's slice of the columns over ALL rows: thread = (row group rg of 16, column lane cl of 16)
+    {
+        const int c = v0 / KG_ROWS;
+        const int cb = (int)((long long)c * W / chunks), ce = (int)((long long)(c + 1) * W / chunks);
+        const int rg = tid >> 4, cl = tid & 15;
+        for (int u0 = cb; u0 < ce; u0 += 16) {                          // block-uniform trip count
+            const int u = u0 + cl;
+            float nlo = -INFINITY, hi = -INFINITY;
+            if (u < ce)
+                for (int v = rg; v < H; v += 16) {
+                    const float* p = sup + ((long long)v * W + u) * 3;
+                    const float x = p[0], z = p[2];
+                    if (z > 0.f && isfinite(x) && isfinite(z)) {
+                        const float a = x / z;
+                        nlo = fmaxf(nlo, -a);
+                        hi = fmaxf(hi, a);
+                    }
+                }
+            snlo[rg][cl] = nlo;
+            shi[rg][cl] = hi;
+            __syncthreads();
+            if (tid < 16 && u0 + tid < ce) {
+                float a = snlo[0][tid], b2 = shi[0][tid];
+                for (int r = 1; r < 16; ++r) {
+                    a = fmaxf(a, snlo[r][tid]);
+                    b2 = fmaxf(b2, shi[r][tid]);
+                }
+                out[u0 + tid] = isinf(a) ? 0u : ord_key(a);
+                out[W + u0 + tid] = isinf(b2) ? 0u : ord_key(b2);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -682,8 +708,13 @@ __global__ __launch_bounds__(KW_BLOCK) void knn_grid_kernel(const KnnTable tab)
         admit(dist2_ref(qx, qy, qz, p[0], p[1], p[2]), gi, live, incl);
     };
 
-    const bool structured = rk[2 * W + 2 * H] == 0u && qz > 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
-    const bool has_hole = rk[2 * W + 2 * H + 1] != 0u;
+    unsigned any_bad = 0u, any_hole = 0u;                                      // the table's flag words, one pair per 16 rows
+    for (int c = 0; c < range_chunks(H); ++c) {
+        any_bad |= rk[2 * W + 2 * H + 2 * c];
+        any_hole |= rk[2 * W + 2 * H + 2 * c + 1];
+    }
+    const bool structured = any_bad == 0u && qz > 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
+    const bool has_hole = any_hole != 0u;
     const float q2 = dist2_ref(qx, qy, qz, 0.f, 0.f, 0.f);
     // this lane's columns lane, lane + 64, ... and rows: plane bounds (0 where the query's own ratio lies inside the range)
     float lbc[KG_MAXDIM / 64], lbr[KG_MAXDIM / 64];
@@ -867,7 +898,7 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
     const gdm_knn_job* rt_job[GDM_KNN_MAX_JOBS];
     const gdm_knn_job* pk_job[GDM_KNN_MAX_JOBS];
     int pack_blocks = 0, range_blocks = 0;
-    size_t used = 0, range_first = 0, range_last = 0;
+    size_t used = 0;
     int nblocks = 0, gblocks = 0;
     for (int a = 0; a < n; ++a) {
         const gdm_knn_job& jb = jobs[order[a]];
@@ -885,8 +916,6 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
                     re.H = jb.S / jb.grid_w;
                     re.ranges = (float*)((char*)workspace + used);
                     re.nblocks = B * gdm_cdiv(re.H, KG_ROWS);
-                    if (rt.n == 0) range_first = used;
-                    range_last = used + need;
                     range_blocks += re.nblocks;
                     rt_job[rt.n++] = &jb;
                     used += need;
@@ -933,9 +962,7 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
     }
     int rc;
     if (rt.n) {
-        // every entry of the range tables is a max-reduction from zero (packed tiles may sit between two tables: they are
-        // written afterwards by knn_pack_kernel, so clearing the whole span is harmless)
-        GDM_HIP(hipMemsetAsync((char*)workspace + range_first, 0, range_last - range_first, stream));
+        // every word of the range tables is written by the kernel itself: no zero fill
         hipLaunchKernelGGL(knn_grid_ranges_kernel, dim3(range_blocks), dim3(256), 0, stream, rt);
         if ((rc = gdm_launch_status("knn_grid_ranges_kernel"))) return rc;
     }
