@@ -502,6 +502,61 @@ __global__ __launch_bounds__(KS * 64) void pointwise_mfma_jobs_kernel(const PwAr
     }
 }
 
+// Two CHAINED narrow layers per point in one launch: y0 = act0(s0 (W0 x) + b0), y1 = act1(s1 (W1 y0) + b1), both written (the RandLA
+// stem: fc0 9 -> 8 and the first block's mlp1 8 -> 16, RandLANet.py:19,683; y0 is also the block's shortcut input).  One thread per
+// point; the sums run in the order of pointwise_kernel (k ascending from 0, fmaf), so both outputs equal the two launches' bit for bit.
+struct PwChain2 {
+    const float* x;                      // [B, C0, n]
+    const float *w0t, *s0, *b0;          // [C0, C1], [C1] or NULL
+    const float *w1t, *s1, *b1;          // [C1, C2]
+    float *y0, *y1;                      // [B, C1, n], [B, C2, n]
+    int n, C0, C1, C2, act0, act1;
+    float slope0, slope1;
+    long total;
+};
+
+__device__ __forceinline__ float pw_act(float y, int act, float slope)
+{
+    if (act == 1) return fmaxf(y, 0.f);
+    if (act == 2) return y > 0.f ? y : y * slope;
+    return y;
+}
+
+__global__ __launch_bounds__(256) void pointwise_chain2_kernel(const PwChain2 a)
+{
+    constexpr int CMAX0 = 16, CMAX1 = 16, CMAX2 = 32;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.total) return;
+    const long b = g / a.n;
+    const int i = (int)(g - b * a.n);
+    float xin[CMAX0];
+#pragma unroll
+    for (int k = 0; k < CMAX0; ++k) xin[k] = k < a.C0 ? a.x[(b * a.C0 + k) * a.n + i] : 0.f;
+    float h[CMAX1];
+#pragma unroll
+    for (int c = 0; c < CMAX1; ++c) {
+        float acc = 0.f;
+        if (c < a.C1) {
+#pragma unroll
+            for (int k = 0; k < CMAX0; ++k)
+                if (k < a.C0) acc = fmaf(a.w0t[k * a.C1 + c], xin[k], acc);
+            acc = pw_act(fmaf(acc, a.s0 ? a.s0[c] : 1.f, a.b0 ? a.b0[c] : 0.f), a.act0, a.slope0);
+            a.y0[(b * a.C1 + c) * a.n + i] = acc;
+        }
+        h[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX2; ++c) {
+        if (c < a.C2) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < CMAX1; ++k)
+                if (k < a.C1) acc = fmaf(a.w1t[k * a.C2 + c], h[k], acc);
+            a.y1[(b * a.C2 + c) * a.n + i] = pw_act(fmaf(acc, a.s1 ? a.s1[c] : 1.f, a.b1 ? a.b1[c] : 0.f), a.act1, a.slope1);
+        }
+    }
+}
+
 bool seg_ok(const gdm_pw_seg& s, int n)
 {
     return s.x && s.C >= 1 && s.n_src >= 1 && (s.idx || s.n_src == n);
@@ -654,4 +709,21 @@ extern "C" int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, 
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int gdm_pointwise_chain2_hip(const float* x, const float* w0t, const float* s0, const float* b0, int act0, float slope0,
+                                        const float* w1t, const float* s1, const float* b1, int act1, float slope1,
+                                        int B, int n, int C0, int C1, int C2, float* y0, float* y1, void* stream)
+{
+    GDM_CHECK_ARG(x && w0t && w1t && y0 && y1, "gdm_pointwise_chain2_hip: NULL pointer");
+    GDM_CHECK_ARG(B >= 1 && n >= 1 && C0 >= 1 && C0 <= 16 && C1 >= 1 && C1 <= 16 && C2 >= 1 && C2 <= 32,
+                  "gdm_pointwise_chain2_hip: B=%d n=%d C0=%d (<= 16) C1=%d (<= 16) C2=%d (<= 32)", B, n, C0, C1, C2);
+    GDM_CHECK_ARG(act0 >= 0 && act0 <= 2 && act1 >= 0 && act1 <= 2, "gdm_pointwise_chain2_hip: act=%d,%d", act0, act1);
+    PwChain2 a;
+    a.x = x; a.w0t = w0t; a.s0 = s0; a.b0 = b0; a.w1t = w1t; a.s1 = s1; a.b1 = b1; a.y0 = y0; a.y1 = y1;
+    a.n = n; a.C0 = C0; a.C1 = C1; a.C2 = C2; a.act0 = act0; a.act1 = act1; a.slope0 = slope0; a.slope1 = slope1;
+    a.total = (long)B * n;
+    GDM_CHECK_ARG(gdm_cdiv(a.total, 256) <= 0x7fffffff, "gdm_pointwise_chain2_hip: grid too large");
+    hipLaunchKernelGGL(pointwise_chain2_kernel, dim3(gdm_cdiv(a.total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return gdm_launch_status("pointwise_chain2_kernel");
 }

@@ -240,7 +240,7 @@ class FFB6DEmb(nn.Module):
             raise RuntimeError("side_first / stage_hook are hooks of the two-stream pipeline")
         if not overlap:
             _pyr.wait_ready(inputs)
-        p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)      # [B,8,N,1]
+        p_emb, f_pc0 = self._stem_and_mlp1(inputs["cld_rgb_nrm"])             # [B,8,N,1] (+ the first block's mlp1 of it)
 
         ds_emb = []
         for i_ds in range(4):
@@ -250,7 +250,7 @@ class FFB6DEmb(nn.Module):
                     if i_ds == 0:
                         _pyr.wait_ready(inputs)                               # the side stream's own wait
                     f.use(p_emb, xyz_i, nei_i, sub_i)
-                    f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, xyz_i, nei_i)
+                    f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, xyz_i, nei_i, f_pc=f_pc0 if i_ds == 0 else None)
                     p_emb0 = self.random_sample(f_encoder_i, sub_i)
                 rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
                 if i_ds == 0:
@@ -258,7 +258,8 @@ class FFB6DEmb(nn.Module):
                 f.join(f_encoder_i, p_emb0)
             else:
                 rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
-                f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
+                f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds],
+                                                         f_pc=f_pc0 if i_ds == 0 else None)
                 p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
             bs, c, hr, wr = rgb_emb0.size()
             if i_ds == 0:
@@ -310,6 +311,18 @@ class FFB6DEmb(nn.Module):
             return rgb_emb_c, p_emb
         return torch.cat([rgb_emb_c, p_emb], dim=1)
 
+    def _stem_and_mlp1(self, x):
+        """The RandLA stem fc0 (RandLANet.py:19) and the first block's mlp1 (:683) as ONE launch of two chained per-point layers
+        (settings.USE_POINT_CHAIN; same sums in the same order as the two launches) -> (p_emb [B,8,N,1], mlp1(p_emb) [B,16,N,1] or None)."""
+        blk = self.rndla_ds_stages[0]
+        if settings.USE_POINT_CHAIN and settings.USE_POINTWISE and fused_eval(x, self) and x.dim() == 3:
+            p0, p1 = self.rndla_pre_stages._pointwise_params(), blk.mlp1._pointwise_params()
+            if (p0 is not None and p1 is not None and p0[0].shape[0] <= 16 and p0[0].shape[1] <= 16 and p1[0].shape[1] <= 32
+                    and p1[0].shape[0] == p0[0].shape[1]):
+                y0, y1 = ops.pointwise_chain2(x, p0, p1)
+                return y0.unsqueeze(3), y1.unsqueeze(3)
+        return self.rndla_pre_stages(x).unsqueeze(3), None
+
     def _forward_two_streams(self, inputs, rgb_emb, parts, side_first=None, stage_hook=None):
         """The inference forward as a two-stream pipeline (settings.USE_SIDE_STREAMS): the IMAGE stream (the current one) runs the
         trunk / up stages and the point-to-pixel fusions, the POINT stream (side stream 0) the RandLA blocks, the decoder layers and the
@@ -341,7 +354,7 @@ class FFB6DEmb(nn.Module):
                 side_first()                                                  # independent work (the mesh branch) in front of the point
                                                                               # stream's wait for the pyramid; joined with the stream at the end
             _pyr.wait_ready(inputs, cloud_only=True)                          # the point stream's own wait: the cloud's searches only
-            p_emb = self.rndla_pre_stages(inputs["cld_rgb_nrm"]).unsqueeze(3)  # [B,8,N,1]
+            p_emb, f_pc0 = self._stem_and_mlp1(inputs["cld_rgb_nrm"])         # [B,8,N,1] (+ the first block's mlp1 of it)
         ds_emb = []
         for i_ds in range(4):
             if stage_hook is not None and stage_hook[0] == i_ds:
@@ -351,7 +364,8 @@ class FFB6DEmb(nn.Module):
             ev_rgb0 = event(M)
             bs, c, hr, wr = rgb_emb0.size()
             with torch.cuda.stream(S):
-                f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds])
+                f_encoder_i = self.rndla_ds_stages[i_ds](p_emb, inputs["cld_xyz%d" % i_ds], inputs["cld_nei_idx%d" % i_ds],
+                                                         f_pc=f_pc0 if i_ds == 0 else None)
                 p_emb0 = self.random_sample(f_encoder_i, inputs["cld_sub_idx%d" % i_ds])
                 pt = self._p2r_point_term(self.ds_fuse_p2r_pre_layers[i_ds], self.ds_fuse_p2r_fuse_layers[i_ds], c, p_emb0)
                 ev_p0 = event(S)

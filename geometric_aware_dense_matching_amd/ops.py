@@ -665,6 +665,24 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_m
     return out
 
 
+def pointwise_chain2(x, p0, p1):
+    """Two chained narrow per-point layers in one launch (include/gdm.h gdm_pointwise_chain2_hip): x f32[B,C0,n]; p0, p1 =
+    (wt [K,Cout], scale, shift, act, slope) as `_FusedConvMixin._pointwise_params` gives them -> (y0 [B,C1,n], y1 [B,C2,n])."""
+    x = _dev(x, torch.float32, "x")
+    B, C0, n = x.shape
+    (w0, s0, b0, a0, sl0), (w1, s1, b1, a1, sl1) = p0, p1
+    C1, C2 = w0.shape[1], w1.shape[1]
+    if w0.shape[0] != C0 or w1.shape[0] != C1:
+        raise ValueError("pointwise_chain2: weights %s, %s do not chain from %d channels" % (tuple(w0.shape), tuple(w1.shape), C0))
+    y0 = torch.empty((B, C1, n), dtype=torch.float32, device=x.device)
+    y1 = torch.empty((B, C2, n), dtype=torch.float32, device=x.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    check(_lib.lib().gdm_pointwise_chain2_hip(x.data_ptr(), w0.data_ptr(), ptr(s0), ptr(b0), int(a0), float(sl0), w1.data_ptr(), ptr(s1), ptr(b1),
+                                              int(a1), float(sl1), B, n, C0, C1, C2, y0.data_ptr(), y1.data_ptr(), _stream()),
+          "gdm_pointwise_chain2_hip")
+    return y0, y1
+
+
 def pointwise_jobs(xs, wts):
     """Up to four independent plain per-point layers of equal K and Cout in ONE launch (include/gdm.h gdm_pointwise_jobs_hip):
     xs[j] f32[B,K,n_j], wts[j] f32[K,Cout] (the weight transposed) -> [f32[B,Cout,n_j]].  Bit-identical to `pointwise([x], wt)` per

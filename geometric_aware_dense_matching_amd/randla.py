@@ -99,8 +99,10 @@ class DilatedResBlock(nn.Module):
         self.mlp2 = rl_conv2d(d_out, d_out * 2, bn=True, activation=None)
         self.shortcut = rl_conv2d(d_in, d_out * 2, bn=True, activation=None)
 
-    def forward(self, feature, xyz, neigh_idx):
-        f_pc = self.mlp1(feature)
+    def forward(self, feature, xyz, neigh_idx, f_pc=None):
+        """f_pc: mlp1(feature) when the caller already has it (ffb6d: the stem layer and this block's mlp1 as one launch)."""
+        if f_pc is None:
+            f_pc = self.mlp1(feature)
         f_pc = self.lfa(xyz, f_pc, neigh_idx)
         if fused_eval(feature, self) and settings.USE_POINTWISE:
             # lrelu(bn(mlp2(f_pc)) + bn(shortcut(feature))): both 1x1 layers, both folded BatchNorms, the sum and the activation in ONE launch

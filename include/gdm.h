@@ -523,6 +523,13 @@ typedef struct {
     int32_t n;
 } gdm_pw_job;
 int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, int K, int Cout, void* stream);
+/* Two chained narrow per-point layers in one launch, both results written: y0 = act0(s0 (W0 x) + b0) f32[B,C1,n],
+ * y1 = act1(s1 (W1 y0) + b1) f32[B,C2,n]; x f32[B,C0,n], w0t f32[C0,C1], w1t f32[C1,C2] (weights transposed), s / b folded
+ * BatchNorm or NULL, act 0 none / 1 ReLU / 2 LeakyReLU(slope); C0, C1 <= 16, C2 <= 32.  The RandLA stem fc0 and the first block's
+ * mlp1 (/root/reference/models/RandLA/RandLANet.py:19,683-684).  Bit-identical to two gdm_pointwise_hip launches. */
+int gdm_pointwise_chain2_hip(const float* x, const float* w0t, const float* s0, const float* b0, int act0, float slope0,
+                             const float* w1t, const float* s1, const float* b1, int act1, float slope1,
+                             int B, int n, int C0, int C1, int C2, float* y0, float* y1, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * The ResNet stem in one launch (inference): conv 7x7 / stride 2 / pad 3 (3 -> 64, no bias) + scale / shift (folded BatchNorm) +

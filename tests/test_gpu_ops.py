@@ -784,6 +784,22 @@ def test_match_pack2_equals_two_pack_launches(ops, prec, R1, n1, n2):
     assert torch.equal(o1, ops.match_pack(a, p)) and torch.equal(o2, ops.match_pack(b, p))
 
 
+@pytest.mark.parametrize("B,n,C0,C1,C2,acts", [(16, 2048, 9, 8, 16, (2, 2)), (3, 77, 16, 16, 32, (1, 0)), (1, 5, 1, 3, 2, (0, 2))])
+def test_pointwise_chain2_equals_two_launches_bit_for_bit(ops, B, n, C0, C1, C2, acts):
+    """gdm_pointwise_chain2_hip (RandLA stem fc0 + the first block's mlp1, RandLANet.py:19,683) == two gdm_pointwise_hip launches."""
+    g = torch.Generator(device="cpu").manual_seed(B + n + C2)
+    x = torch.randn(B, C0, n, generator=g).cuda()
+    mk = lambda k, c: ((torch.randn(k, c, generator=g) / k ** 0.5).cuda(), (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda())
+    (w0, s0, b0), (w1, s1, b1) = mk(C0, C1), mk(C1, C2)
+    y0, y1 = ops.pointwise_chain2(x, (w0, s0, b0, acts[0], 0.2), (w1, s1, b1, acts[1], 0.2))
+    r0 = ops.pointwise([x], w0, s0, b0, acts[0], 0.2)
+    r1 = ops.pointwise([r0], w1, s1, b1, acts[1], 0.2)
+    assert torch.equal(y0, r0) and torch.equal(y1, r1)
+    y0n, y1n = ops.pointwise_chain2(x, (w0, None, None, 0, 0.0), (w1, None, b1, 1, 0.0))          # no scale / shift
+    r0n = ops.pointwise([x], w0)
+    assert torch.equal(y0n, r0n) and torch.equal(y1n, ops.pointwise([r0n], w1, None, b1, 1, 0.0))
+
+
 def test_pointwise_jobs_mixed_k_splits_and_bad_shapes(ops):
     x = torch.randn(2, 64, 8, device="cuda")
     with pytest.raises(ValueError):
