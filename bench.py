@@ -580,9 +580,13 @@ def main():
             torch.cuda.synchronize()
             ref2 = {k: v.clone() for k, v in step().items()}
             torch.cuda.synchronize()
+            # with several ranks a process has helper threads of the collective backend (RCCL watchdog / heartbeat) that may touch the
+            # HIP runtime while this thread captures: in the default "global" mode such a call invalidates the capture.  "thread_local"
+            # restricts the check to the capturing thread; one rank captures as it always did.
+            cap_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **cap_kw):
                     graph_out = step()
                 graph.replay()
                 graph.replay()                                 # twice: the second replay also reads what the first one left behind
@@ -608,7 +612,7 @@ def main():
                         step(pool=forked_pool)
                     torch.cuda.synchronize()
                     graph_forked = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_forked):
+                    with torch.cuda.graph(graph_forked, **cap_kw):
                         forked_out = step(pool=forked_pool)
                     graph_forked.replay()
                     graph_forked.replay()
