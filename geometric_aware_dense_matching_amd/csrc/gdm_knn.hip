@@ -87,6 +87,7 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float p
 // t, t + T, ... of each tile, strict '<'), same merge: results identical to knn_kernel<1>.
 typedef __attribute__((ext_vector_type(2))) float knn_f32x2;
 
+template <int VAR>
 __global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab)
 {
     __shared__ float4 tile[KNN_TILE];
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab
     const float* qr0 = job.query + (long long)b * job.query_bstride + (long long)qc0 * 3;
     const float* qr1 = job.query + (long long)b * job.query_bstride + (long long)qc1 * 3;
     const knn_f32x2 qx = {qr0[0], qr1[0]}, qy = {qr0[1], qr1[1]}, qz = {qr0[2], qr1[2]};
+    knn_f32x2 nqx = -qx, nqy = -qy, nqz = -qz;                  // VAR 1: no neg modifier, no op_sel broadcast, no dest = source pair
+    if (VAR == 1) asm volatile("" : "+v"(nqx), "+v"(nqy), "+v"(nqz));
     float d0 = INFINITY, d1 = INFINITY;
     int i0 = IDX_EMPTY, i1 = IDX_EMPTY;
     for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
@@ -132,13 +135,31 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab
 #endif
         for (int s = 0; s < steps; ++s) {
             const int p = (s << logT) + t;
-            const float4 v = tile[p];
+            float4 v = tile[p];
+            if (VAR == 2) asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z));    // VAR 2: two wait states between the LDS return and the packed ops
 #ifdef GDM_K1P_SCALAR
             knn_f32x2 r;
             r.x = dist2_ref(qx.x, qy.x, qz.x, v.x, v.y, v.z);
             r.y = dist2_ref(qx.y, qy.y, qz.y, v.x, v.y, v.z);
 #else
-            const knn_f32x2 ex = qx - knn_f32x2{v.x, v.x}, ey = qy - knn_f32x2{v.y, v.y}, ez = qz - knn_f32x2{v.z, v.z};
+            knn_f32x2 ex, ey, ez;
+            if (VAR == 1) {
+                knn_f32x2 bx = {v.x, v.x}, by = {v.y, v.y}, bz = {v.z, v.z};
+                asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz));     // the broadcast as real register pairs: (v - q)^2 == (q - v)^2 bit for bit
+                ex = bx + nqx; ey = by + nqy; ez = bz + nqz;
+            } else if (VAR == 3) {
+                // the x op (high result <- LOW register of the LDS pair) straight behind the LDS wait, two wait states, then the y op
+                // (low result <- HIGH register) and z: separates "any immediate packed consumer" from "the op_sel:[0,1] form"
+                knn_f32x2 vxy = {v.x, v.y};
+                asm volatile("v_pk_add_f32 %0, %2, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                             "s_nop 1\n\t"
+                             "v_pk_add_f32 %1, %3, %4 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                             "s_nop 0"
+                             : "=&v"(ex), "=&v"(ey) : "v"(qx), "v"(qy), "v"(vxy));
+                ez = qz - knn_f32x2{v.z, v.z};
+            } else {
+                ex = qx - knn_f32x2{v.x, v.x}; ey = qy - knn_f32x2{v.y, v.y}; ez = qz - knn_f32x2{v.z, v.z};
+            }
             knn_f32x2 r = ex * ex;
             r = r + ey * ey;
             r = r + ez * ez;
@@ -826,7 +847,7 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     static int pair_env = -1;
     if (pair_env < 0) {
         const char* e = getenv("GDM_KNN1_PAIR");
-        pair_env = (e && e[0] == '1') ? 1 : 0;
+        pair_env = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0;
     }
     const bool pair = pair_env != 0;
     KnnTable tab;
@@ -844,7 +865,10 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
     }
     if (tab.njobs == 0) return 0;
     if (pair) {
-        hipLaunchKernelGGL(knn1_pair_kernel, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+        if (pair_env == 2) hipLaunchKernelGGL(knn1_pair_kernel<1>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+        else if (pair_env == 3) hipLaunchKernelGGL(knn1_pair_kernel<2>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+        else if (pair_env == 4) hipLaunchKernelGGL(knn1_pair_kernel<3>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
+        else hipLaunchKernelGGL(knn1_pair_kernel<0>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
         return gdm_launch_status("knn1_pair_kernel");
     }
     hipLaunchKernelGGL(knn_kernel<1>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);

@@ -61,6 +61,10 @@ def _stream_lane(device):
     for (d, which), st in _side_streams.items():
         if d == idx and st.cuda_stream == h:
             return ("side", which)
+    # The process-wide default pool has no owner that could promise "one step at a time": two eager callers on different user
+    # streams must not share a zero-bordered operand buffer or a matching workspace, so there the handle is part of the key.
+    if _pool is _default_pool:
+        return ("main", h)
     return "main"
 
 

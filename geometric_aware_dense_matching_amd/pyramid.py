@@ -26,6 +26,12 @@ def cloud_from_inputs(cld_rgb_nrm):
     return cld_rgb_nrm[:, :3, :].transpose(1, 2).contiguous()
 
 
+def cloud_view(cld_rgb_nrm):
+    """cld_rgb_nrm f32[B,9,N] -> xyz f32[B,N,3] as a VIEW of the loader's tensor (no launch): build_pyramid makes it dense inside its
+    own copy launch, together with the strided pixel grids and the prefix sub-clouds."""
+    return cld_rgb_nrm[:, :3, :].transpose(1, 2)
+
+
 READY = "_pyramid_ready"          # key of the event recorded behind an overlapped pyramid build
 READY_CLOUD = "_pyramid_ready_cloud"   # ... and of the one behind its first part: the cloud's own K = 16 searches and pooling indices
 KEEP = "_pyramid_keep"            # key of the buffers the build keeps alive with its results (kNN workspace, strided grids)
@@ -56,18 +62,27 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
     assert dpt_xyz.shape == (B, S, S, 3)
     if N % 256 != 0 or N < 1024:
         raise ValueError("N=%d: four /4 levels must leave >= 16 points (N >= 1024, N %% 256 == 0)" % N)
-    cld = cld.contiguous()
     dpt_xyz = dpt_xyz.contiguous()
     n_lv = [N]
     for i in range(4):
         n_lv.append(n_lv[-1] // PCLD_SUB_SR[i])
     # the strided xyz maps (linemod_pbr.py:517-527) and the prefix sub-clouds (:538), dense, in ONE copy launch.  (The searches
-    # could read the prefix views in place -- batch stride kept -- but every later consumer wants them dense.)
-    dense = ops.copy_views([dpt_xyz[:, ::sc, ::sc, :] for sc in (2, 4, 8)] + [cld[:, :n_lv[i]] for i in (1, 2, 3, 4)])
+    # could read the prefix views in place -- batch stride kept -- but every later consumer wants them dense.)  A cloud that arrives
+    # as a view of the loader's channel-major tensor (cloud_view) is made dense by the same launch: [B,n,3,1] views, whose last
+    # dimension is trivially contiguous.
+    if cld.is_contiguous():
+        cviews = [cld[:, :n_lv[i]] for i in (1, 2, 3, 4)]
+    else:
+        cviews = [cld[:, :n].unsqueeze(-1) for n in n_lv]
+    dense = ops.copy_views([dpt_xyz[:, ::sc, ::sc, :] for sc in (2, 4, 8)] + cviews)
     grids = {1: dpt_xyz.reshape(B, S * S, 3)}
     for sc, g in zip((2, 4, 8), dense[:3]):
         grids[sc] = g.reshape(B, -1, 3)
-    levels = [cld] + dense[3:]
+    if cld.is_contiguous():
+        levels = [cld] + dense[3:]
+    else:
+        levels = [t.squeeze(-1) for t in dense[3:]]
+        dense = dense[:3] + levels
 
     jobs, names = [], []
     for i in range(4):

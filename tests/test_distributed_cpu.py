@@ -88,3 +88,50 @@ def test_train_cli_flags_match_the_reference():
     assert (a.gpus, a.state, a.dataset_name, a.cls_id, a.checkpoint) == (2, "train", "lmo", 1, "ck/")
     a = train_lm.build_parser().parse_args("--gpus=0 -state=test".split())
     assert a.state == "test" and a.cls_id == 5 and a.bn_momentum == 0.9 and a.decay_step == 2e5
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the flag was parsed and never read): the parent starts two
+    fresh ranks through torch.distributed.run BEFORE importing torch (nothing in the parent touches the GPU), rank 0's JSON line
+    comes back on the parent's stdout, the exit code is the children's.  --probe-ranks keeps it to the rendezvous (gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--probe-ranks"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_ranks_seen"] == 2 and rec["world_size"] == 2 and rec["spawned_by_bench"] and not rec["torch_cuda_initialised"]
+    # the parent: launch_ranks() builds the reference-shaped launch line and has not imported torch when it runs it
+    code = ("import sys, json; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "seen = {}\n"
+            "class R:\n    returncode = 7\n"
+            "def run(cmd, env):\n    seen['cmd'] = cmd; seen['torch'] = 'torch' in sys.modules; seen['env'] = env.get('GDM_BENCH_SPAWNED'); return R()\n"
+            "argv = ['--gpus', '4', '--steps', '3']\n"
+            "rc = bench.launch_ranks(bench.parse(argv), argv, run=run)\n"
+            "print(json.dumps(dict(seen, rc=rc)))\n" % root)
+    q = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert q.returncode == 0, q.stderr[-2000:]
+    seen = json.loads(q.stdout.strip().splitlines()[-1])
+    assert seen["rc"] == 7 and seen["torch"] is False and seen["env"] == "1"
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_exact_f32_flag_covers_every_split_bf16_switch():
+    """bench.py --exact-f32 zeroes the environment variable of EVERY switch in settings.SPLIT_BF16_SWITCHES (a hard-coded
+    list had missed USE_OWN_STEM)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from geometric_aware_dense_matching_amd import settings
+    envs = bench.exact_f32_env()
+    assert len(envs) == len(settings.SPLIT_BF16_SWITCHES) and "GDM_OWN_STEM" in envs
+    for name, env in zip(settings.SPLIT_BF16_SWITCHES, envs):
+        assert env == "GDM_" + name[len("USE_"):], (name, env)
