@@ -30,6 +30,15 @@ constexpr int CV_THREADS = 512;           // 8 waves
 constexpr int CV_PIX = 256;               // pixels per workgroup (32 per wave)
 constexpr int CV_CO = 128;                // output channels per workgroup
 constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
+#ifndef GDM_CONV_TAP_INNER
+#define GDM_CONV_TAP_INNER 1             // 1: panels chunk-major (nine taps of a chunk back to back); 0: tap-major (rounds 1-3)
+#endif
+#ifndef GDM_CONV16_PF
+#define GDM_CONV16_PF 2
+#endif
+#ifndef GDM_CONV_GLDS
+#define GDM_CONV_GLDS 1                  // 1: weight panels of the 16x16x32 kernel by LDS-DMA (eight-wave workgroups); 0: through registers
+#endif
 #ifndef GDM_CONV_EXP
 #define GDM_CONV_EXP 0                   // development: 1 = no weight staging / barrier after panel 0, 2 = no operand reloads (wrong results)
 #endif
@@ -139,9 +148,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     // hipcc drains vmcnt to 0 at a loop back-edge for loads consumed in the next iteration, so nothing may be issued late in
     // the body (a load issued just before the back-edge exposes its whole latency to all 8 waves at once).
     u32x4 ahi[8], alo[8];                                           // fragments of k-step s: ahi[s], alo[s]
+    // Panel order: chunk-major, the nine taps of a 128-channel chunk back to back (GDM_CONV_TAP_INNER, default).  The activation
+    // operand of a chunk is re-read once per tap; tap-major order puts nchunk panels (~1.3 MB per XCD each) between two reads of the
+    // same planes, more than the XCD's 4 MB L2 holds at nchunk = 4 -- every re-read then came from beyond L2 (PMC round 3: 406 MB
+    // fetched for 81 MB of operands) with that latency in front of the panel's first MFMA.
+    auto panel_tc = [&](int it, int& tap, int& chunk) {
+        if (TAPS == 1) { tap = 4; chunk = it; }
+        else if (GDM_CONV_TAP_INNER) { chunk = it / TAPS; tap = it - chunk * TAPS; }
+        else { tap = it / nchunk; chunk = it - tap * nchunk; }
+    };
     auto a_row = [&](int it) {
-        const int tap = (TAPS == 1) ? 4 : it / nchunk;
-        const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
+        int tap, chunk;
+        panel_tc(it, tap, chunk);
         const int ky = tap / 3, kx = tap - ky * 3;
         return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + h) * plane + pixbase + (long)ky * (W + 2) + kx) * 16;
     };
@@ -152,7 +170,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsign
     };
     u32x4 stage[8];
     auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
-        const unsigned char* src = wpk + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
+        int tap, chunk;
+        panel_tc(it, tap, chunk);
+        const int wit = (TAPS == 1) ? it : tap * nchunk + chunk;   // the packed weights stay (tap, chunk, co) rows
+        const unsigned char* src = wpk + ((long)wit * ((Cout + 127) & ~127) + co0) * ROWB;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = i * CV_THREADS + tid;
@@ -383,7 +404,8 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     constexpr int TST = NCB * 16 + 4;                               // floats per pixel row of a wave's output tile in LDS
     static_assert(NCB == 8 || (NCB == 4 && !PIXMAJOR), "64-channel tiles: NCHW / packed output only");
     constexpr int NPH = MF_NPH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform FOR THE COMPILER too: everything derived from it stays scalar
     const int l16 = lane & 15, kg = lane >> 4;                      // row inside a 16-row fragment, 8-channel group inside a k-step
     const int nchunk = (Cin + 127) / 128;
     const int npanel = TAPS * nchunk;
@@ -391,49 +413,65 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
     const unsigned bx = co_fastest ? blockIdx.y : blockIdx.x, by = co_fastest ? blockIdx.x : blockIdx.y;
     const long pix0 = (long)bx * (WV * MF_WPIX) + wave * MF_WPIX;           // this wave's first pixel
-    const int co0 = tile_co0 ? tile_co0[bx] : by * (NCB * 16);
+    const int co0 = tile_co0 ? __builtin_amdgcn_readfirstlane(tile_co0[bx]) : by * (NCB * 16);
     const long pc = min(pix0, ptot - MF_WPIX);
     const int b = (int)(pc / hw);                                   // one image per wave (hw % MF_WPIX == 0)
     const int prem = (int)(pc - (long)b * hw);
     const int Wi = W * stride;
     const long plane = (long)(H * stride + 2) * (Wi + 2);           // input planes (operand loads)
     const long oplane = (long)(H + 2) * (W + 2);                    // output planes (packed epilogue)
-    long pixbase[NPH];                                              // fragment ph: 16 consecutive pixels of one image row (W % 16 == 0)
+    // Operand loads are BUFFER loads: descriptor over the packed activations, per-lane byte offset fixed for the whole kernel
+    // (plane kg of a k-step + the lane's pixel), everything that changes per panel / tap / k-step in the SCALAR offset.  The flat
+    // form recomputed a 64-bit per-lane address for every load (v_mad_u64 / v_lshl_add_u64 / v_mul_lo clumps of ~45 vector
+    // instructions at the head of each half panel, issued by both waves of a SIMD at once right behind the barrier: MFMA pipe idle).
+    // The host checks that both packed buffers are below 2 GiB.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xpk), (short)0, 0x7ffffff0, 0x00020000);
+    int avoff[NPH];                                                 // fragment ph: 16 consecutive pixels of one image row (W % 16 == 0)
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int pr = prem + 16 * ph;
         const int yy = pr / W, xx = pr - yy * W;
-        pixbase[ph] = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)(yy * stride) * (Wi + 2) + (long)(xx + l16) * stride;
+        const long pixbase = rowidx ? (long)max(rowidx[pc + l16 + 16 * ph], 0) : (long)(yy * stride) * (Wi + 2) + (long)(xx + l16) * stride;
+        avoff[ph] = (int)(((long)kg * plane + pixbase) * 16);
     }
 
     u32x4 ahi[NS][NPH], alo[NS][NPH];                               // fragments of k-step S, pixel fragment ph
-    auto a_row = [&](int it) {                                      // plane kg of the panel's chunk, tap-shifted, pixel 0
-        const int tap = (TAPS == 1) ? 4 : it / nchunk;
-        const int chunk = (TAPS == 1) ? it : it - tap * nchunk;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + kg) * plane + (long)ky * (Wi + 2) + kx) * 16;
+    // Panel bookkeeping in scalar registers, advanced by counters (no division in the loop): panel = (chunk, ky, kx), chunk-major
+    // (GDM_CONV_TAP_INNER, see conv3x3_bf16x3_kernel) or tap-major.  pan_a / pan_w: byte offsets of a panel's operand rows / weight rows.
+    struct Pan { int chunk, ky, kx; };
+    auto pan_next = [&](Pan p) -> Pan {
+        if (TAPS == 1) { ++p.chunk; return p; }
+        if (GDM_CONV_TAP_INNER) {
+            if (++p.kx == 3) { p.kx = 0; if (++p.ky == 3) { p.ky = 0; ++p.chunk; } }
+        } else {
+            if (++p.chunk == nchunk) { p.chunk = 0; if (++p.kx == 3) { p.kx = 0; ++p.ky; } }
+        }
+        return p;
     };
-    const long sstride = 4 * plane * 16;                            // plane 4 S + kg -> 4 (S + 1) + kg
-    const long lostride = 16 * plane * 16;                          // hi plane q -> lo plane 16 + q
-    auto load_a = [&](const unsigned char* r, int S) {
+    const int a_base = (int)(((long)(rowidx ? 0 : b) * nchunk * 32) * plane * 16);
+    const int a_chunk = (int)(32 * plane * 16), a_rowb = (Wi + 2) * 16;
+    auto pan_a = [&](Pan p) -> int { return a_base + p.chunk * a_chunk + p.ky * a_rowb + p.kx * 16; };
+    const int sstride = (int)(4 * plane * 16);                      // plane 4 S + kg -> 4 (S + 1) + kg
+    const int lostride = (int)(16 * plane * 16);                    // hi plane q -> lo plane 16 + q
+    auto load_a = [&](int r, int S) {
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            ahi[S][ph] = *reinterpret_cast<const u32x4*>(r + S * sstride + pixbase[ph] * 16);
-            alo[S][ph] = *reinterpret_cast<const u32x4*>(r + S * sstride + lostride + pixbase[ph] * 16);
+            ahi[S][ph] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, avoff[ph], r + S * sstride, 0));
+            alo[S][ph] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, avoff[ph], r + S * sstride + lostride, 0));
         }
     };
     // a weight panel is staged in two halves (global -> registers -> LDS), each half in flight for half a panel: 16 registers
     constexpr int THREADS = WV * 64, WGPIX = WV * MF_WPIX;
     constexpr int HS = (NCB * 512 / THREADS) / 2;
     u32x4 stage[HS];
-    const unsigned char* wpk_b = wpk + (wbstride ? ((long)bx * WGPIX / hw) * wbstride : 0);
-    auto stage_load = [&](int it, int half) {
-        const unsigned char* src = wpk_b + ((long)it * ((Cout + 127) & ~127) + co0) * ROWB;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wpk), (short)0, 0x7ffffff0, 0x00020000);
+    const int w_base = (wbstride ? (int)(((long)bx * WGPIX / hw) * wbstride) : 0) + co0 * ROWB;
+    const int w_panel = ((Cout + 127) & ~127) * ROWB;               // the packed weights are (tap, chunk, co) rows
+    auto pan_w = [&](Pan p) -> int { return w_base + ((TAPS == 1) ? p.chunk : (p.ky * 3 + p.kx) * nchunk + p.chunk) * w_panel; };
+    auto stage_load = [&](int src, int half) {
 #pragma unroll
-        for (int i = 0; i < HS; ++i) {
-            const int g = (half * HS + i) * THREADS + tid;
-            stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
-        }
+        for (int i = 0; i < HS; ++i)
+            stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, tid * 16, src + (half * HS + i) * THREADS * 16, 0));
     };
     auto stage_store = [&](int buf, int half) {
         unsigned char* base = smem + buf * PANEL;
@@ -442,6 +480,25 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             const int g = (half * HS + i) * THREADS + tid;
             *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
         }
+    };
+    // GLDS (eight-wave workgroups): the weight panel goes global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers and no
+    // ds_write pass.  A wave instruction fills 1 KiB = two 512-byte rows LINEARLY (LDS address = M0 base + lane * 16), so the XOR
+    // swizzle of the LDS image sits on the per-lane SOURCE offset: lane p of piece j = 8 i + wave writes slot p & 31 of row
+    // col = 2 j + (p >> 5), which must hold chunk ch = (s & 16) | ((s ^ col) & 15) of that row (swz is an involution); 2 j = 16 i + 2 wave,
+    // so col & 15 -- and with it the lane's source offset -- is the same for every piece of a wave.
+    constexpr bool GLDS = GDM_CONV_GLDS && WV == 8;
+    constexpr int NPIECE = PANEL / 1024 / 8;                        // LDS-DMA instructions per wave and panel
+    int glds_voff = 0;
+    if (GLDS) {
+        const int hrow = lane >> 5, sl = lane & 31;
+        const int col15 = (2 * wave + hrow) & 15;
+        glds_voff = wave * 1024 + hrow * 512 + (((sl & 16) | ((sl ^ col15) & 15)) << 4);
+    }
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    auto stage_glds = [&](int src, int buf) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(smem + buf * PANEL + (i * 8 + wave) * 1024), 16, glds_voff, src + i * 8192, 0, 0);
     };
 
     f32x4 acc[NPH][NCB];
@@ -453,23 +510,26 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             for (int i = 0; i < 4; ++i) acc[ph][cb][i] = 0.f;
 
     constexpr int LATE = GDM_CONV16_LATE < NS ? GDM_CONV16_LATE : NS;                           // k-steps whose reload is deferred to the next iteration's top
-    stage_load(0, 0);
-    stage_store(0, 0);
-    stage_load(0, 1);
-    stage_store(0, 1);
-    {
-        const unsigned char* r0 = a_row(0);
-#pragma unroll
-        for (int S = 0; S < NS - LATE; ++S) load_a(r0, S);
+    Pan pcur = {0, (TAPS == 1) ? 1 : 0, (TAPS == 1) ? 1 : 0};
+    if (GLDS) {
+        stage_glds(pan_w(pcur), 0);
+    } else {
+        stage_load(pan_w(pcur), 0);
+        stage_store(0, 0);
+        stage_load(pan_w(pcur), 1);
+        stage_store(0, 1);
     }
+    int rcur = pan_a(pcur);
+#pragma unroll
+    for (int S = 0; S < NS - LATE; ++S) load_a(rcur, S);
+    Pan pnxt = npanel > 1 ? pan_next(pcur) : pcur;
+    int rnext = pan_a(pnxt), wnext = pan_w(pnxt);                   // (a harmless re-read of the same rows behind the last panel)
     for (int it = 0; it < npanel; ++it) {
         __syncthreads();                                            // panel `it` is in LDS; panel it-1's readers are done
         const bool more = it + 1 < npanel;
-        const unsigned char* rcur = a_row(it);
-        const unsigned char* rnext = a_row(more ? it + 1 : it);
         const unsigned char* base = smem + (it & 1) * PANEL;
         // units of (k-step S, pair of 16-channel output blocks): 6 NPH MFMAs of 16 cycles on 4 B fragments; PF units' reads in flight
-        constexpr int PF = 2;
+        constexpr int PF = GDM_CONV16_PF;
         constexpr int NU = NPR * NS;
         u32x4 fh[PF + 1][2], fl[PF + 1][2];
         auto frag_load = [&](int un) {
@@ -516,12 +576,12 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                     }
 #endif
             if (pr == NPR - 1 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
-            if (u == NU / 2 && more) {                              // the other buffer's readers finished at this panel's barrier
+            if (!GLDS && u == NU / 2 && more) {                     // the other buffer's readers finished at this panel's barrier
                 stage_store((it + 1) & 1, 0);
-                stage_load(it + 1, 1);
+                stage_load(wnext, 1);
             }
             if (u == 0) {
-                if (more) stage_load(it + 1, 0);
+                if (more) { if (GLDS) stage_glds(wnext, (it + 1) & 1); else stage_load(wnext, 0); }
 #pragma unroll
                 for (int S2 = NS - LATE; S2 < NS; ++S2) load_a(rcur, S2);
             }
@@ -532,7 +592,13 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stage_store((it + 1) & 1, 1);
+        if (!GLDS && more) stage_store((it + 1) & 1, 1);
+        // the next panels' scalar offsets, formed here -- behind the panel's last MFMA, in front of the barrier -- instead of at the
+        // head of the next panel, where both waves of a SIMD would run the same ~40 scalar instructions with the matrix pipe idle
+        rcur = rnext;
+        if (it + 2 < npanel) pnxt = pan_next(pnxt);
+        rnext = pan_a(pnxt);
+        wnext = pan_w(pnxt);
     }
 
     // ---- epilogue: lane = output channel 16 cb + l16, registers = 4 consecutive pixels 16 ph + 4 kg + r ----

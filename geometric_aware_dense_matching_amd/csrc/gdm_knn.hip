@@ -70,8 +70,8 @@ struct KnnTable {
 __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float px, float py, float pz)
 {
     // nanoflann.hpp:343-346 for dim == 3: result = ((0 + d0*d0) + d1*d1) + d2*d2, diff = query - point.  Scalar, explicitly rounded
-    // operations (a packed x / y form -- v_pk_add_f32 / v_pk_mul_f32, same bits -- was measured: no faster, and see the note at
-    // knn1_pair_kernel's launch about packed arithmetic under concurrent replays)
+    // operations (a packed x / y form -- v_pk_add_f32 / v_pk_mul_f32, same bits -- was measured: no faster; and a packed-fp32 read of a
+    // register straight behind the LDS wait that retires it is not safe on this part: profiles/r04_knn1_pair_root_cause.md)
     const float d0 = __fsub_rn(qx, px);
     const float d1 = __fsub_rn(qy, py);
     const float d2 = __fsub_rn(qz, pz);
@@ -79,118 +79,6 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float p
     r = __fadd_rn(r, __fmul_rn(d1, d1));
     r = __fadd_rn(r, __fmul_rn(d2, d2));
     return r;
-}
-
-// K == 1 with TWO queries per lane and the distance arithmetic on the packed fp32 ALU (v_pk_add_f32 / v_pk_mul_f32: two IEEE fp32
-// operations per instruction, each component rounded exactly like the scalar form; -ffp-contract=off keeps mul and add apart): one LDS
-// read and 8 packed + 4 scalar vector instructions per TWO pairs instead of 10 per pair.  Same scan order per query (support points
-// t, t + T, ... of each tile, strict '<'), same merge: results identical to knn_kernel<1>.
-typedef __attribute__((ext_vector_type(2))) float knn_f32x2;
-
-template <int VAR>
-__global__ __launch_bounds__(KNN_BLOCK) void knn1_pair_kernel(const KnnTable tab)
-{
-    __shared__ float4 tile[KNN_TILE];
-    const int bid = blockIdx.x;
-    int j = 0;
-    while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
-    const KnnJobDev& job = tab.jobs[j];
-    const int local = bid - job.block_begin;
-    const int b = local / job.blocks_per_b;
-    const int qb = local - b * job.blocks_per_b;
-    const int logT = job.logT;
-    const int T = 1 << logT;
-    const int S = job.S, Q = job.Q;
-    const int tid = threadIdx.x;
-    const int t = tid & (T - 1);
-    const int qpb = KNN_BLOCK >> logT;                         // queries per block and slot
-    const int q0 = qb * (2 * qpb) + (tid >> logT), q1 = q0 + qpb;
-    const bool valid0 = q0 < Q, valid1 = q1 < Q;
-    const int qc0 = valid0 ? q0 : Q - 1, qc1 = valid1 ? q1 : Q - 1;
-    const float* sup = job.support + (long long)b * job.support_bstride;
-    const float* qr0 = job.query + (long long)b * job.query_bstride + (long long)qc0 * 3;
-    const float* qr1 = job.query + (long long)b * job.query_bstride + (long long)qc1 * 3;
-    const knn_f32x2 qx = {qr0[0], qr1[0]}, qy = {qr0[1], qr1[1]}, qz = {qr0[2], qr1[2]};
-    knn_f32x2 nqx = -qx, nqy = -qy, nqz = -qz;                  // VAR 1: no neg modifier, no op_sel broadcast, no dest = source pair
-    if (VAR == 1) asm volatile("" : "+v"(nqx), "+v"(nqy), "+v"(nqz));
-    float d0 = INFINITY, d1 = INFINITY;
-    int i0 = IDX_EMPTY, i1 = IDX_EMPTY;
-    for (int tile0 = 0; tile0 < S; tile0 += KNN_TILE) {
-        __syncthreads();
-        const int npt = min(KNN_TILE, S - tile0);
-        for (int p = tid; p < KNN_TILE; p += KNN_BLOCK) {
-            float4 v;
-            if (p < npt) {
-                const float* s3 = sup + (long long)(tile0 + p) * 3;
-                v = make_float4(s3[0], s3[1], s3[2], 0.f);
-            } else {
-                v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-            }
-            tile[p] = v;
-        }
-        __syncthreads();
-        const int steps = (npt + T - 1) >> logT;
-#ifndef GDM_K1P_NOUNROLL
-#pragma unroll 4
-#endif
-        for (int s = 0; s < steps; ++s) {
-            const int p = (s << logT) + t;
-            float4 v = tile[p];
-            if (VAR == 2) asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z));    // VAR 2: two wait states between the LDS return and the packed ops
-#ifdef GDM_K1P_SCALAR
-            knn_f32x2 r;
-            r.x = dist2_ref(qx.x, qy.x, qz.x, v.x, v.y, v.z);
-            r.y = dist2_ref(qx.y, qy.y, qz.y, v.x, v.y, v.z);
-#else
-            knn_f32x2 ex, ey, ez;
-            if (VAR == 1) {
-                knn_f32x2 bx = {v.x, v.x}, by = {v.y, v.y}, bz = {v.z, v.z};
-                asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz));     // the broadcast as real register pairs: (v - q)^2 == (q - v)^2 bit for bit
-                ex = bx + nqx; ey = by + nqy; ez = bz + nqz;
-            } else if (VAR == 3) {
-                // the x op (high result <- LOW register of the LDS pair) straight behind the LDS wait, two wait states, then the y op
-                // (low result <- HIGH register) and z: separates "any immediate packed consumer" from "the op_sel:[0,1] form"
-                knn_f32x2 vxy = {v.x, v.y};
-                asm volatile("v_pk_add_f32 %0, %2, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                             "s_nop 1\n\t"
-                             "v_pk_add_f32 %1, %3, %4 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                             "s_nop 0"
-                             : "=&v"(ex), "=&v"(ey) : "v"(qx), "v"(qy), "v"(vxy));
-                ez = qz - knn_f32x2{v.z, v.z};
-            } else {
-                ex = qx - knn_f32x2{v.x, v.x}; ey = qy - knn_f32x2{v.y, v.y}; ez = qz - knn_f32x2{v.z, v.z};
-            }
-            knn_f32x2 r = ex * ex;
-            r = r + ey * ey;
-            r = r + ez * ez;
-#endif
-#ifdef GDM_K1P_B128
-            const int pi = tile0 + p + (__float_as_int(v.w) & 0);          // keeps the fourth component (a 16-byte LDS read)
-#else
-            const int pi = tile0 + p;
-#endif
-            const bool c0 = r.x < d0, c1 = r.y < d1;              // strict: an equal distance has a larger index
-            d0 = c0 ? r.x : d0; i0 = c0 ? pi : i0;
-            d1 = c1 ? r.y : d1; i1 = c1 ? pi : i1;
-        }
-    }
-    // merge the T partial results of each query: lexicographic (d, idx) arg-min
-    for (int m = 1; m < T; m <<= 1) {
-        const float od0 = __shfl_xor(d0, m, 64), od1 = __shfl_xor(d1, m, 64);
-        const int oi0 = __shfl_xor(i0, m, 64), oi1 = __shfl_xor(i1, m, 64);
-        if (od0 < d0 || (od0 == d0 && oi0 < i0)) { d0 = od0; i0 = oi0; }
-        if (od1 < d1 || (od1 == d1 && oi1 < i1)) { d1 = od1; i1 = oi1; }
-    }
-    if (t == 0) {
-        if (valid0) {
-            job.idx[(long long)b * Q + q0] = i0 == IDX_EMPTY ? 0 : i0;
-            if (job.d2) job.d2[(long long)b * Q + q0] = isinf(d0) ? 3.402823466e+38f : d0;
-        }
-        if (valid1) {
-            job.idx[(long long)b * Q + q1] = i1 == IDX_EMPTY ? 0 : i1;
-            if (job.d2) job.d2[(long long)b * Q + q1] = isinf(d1) ? 3.402823466e+38f : d1;
-        }
-    }
 }
 
 template <int KMAX>
@@ -833,23 +721,6 @@ void fill_job(KnnJobDev& d, const gdm_knn_job& j)
 // K == 1 jobs: per-lane best + shuffle merge
 int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
 {
-    // GDM_KNN1_PAIR=1: two queries per lane on the packed fp32 ALU (knn1_pair_kernel; 47.8 -> 39.4 us for 512 x 16384).  NOT the
-    // default: correct in every ordered run (all parity tests), but in forked hipGraph replays launched back to back -- the pyramid on
-    // its side stream beside the previous replay's model kernels -- a few K = 1 results per ~10 replays came out as if single support
-    // points had been missing from the LDS tile (tools/diag_fork_race.py: 20-90 differing arrays in 40 rounds of 5 replays; 0 with
-    // knn_kernel<1>, 0 with a synchronize between replays).  That was with the K = 1 launch directly behind the pyramid's first copy
-    // kernel; since the pyramid is built in two parts (the K = 1 launch now follows knn_wave_kernel and the second copy) the same
-    // stress shows 0 with this kernel too.  Back in the old order (GDM_PYR_SINGLE=1) the variants separate: -DGDM_K1P_SCALAR (same
-    // kernel, the two queries' distances through dist2_ref) 0 differing arrays in 40 rounds, the packed forms (as is / no unroll /
-    // 16-byte LDS reads) 147-166 -- so it is the packed distance arithmetic of THIS kernel (v_pk_add_f32 with op_sel broadcast + neg
-    // modifiers, destination = a source pair) under concurrent execution, not its structure; ordered runs are bit-exact.  Not
-    // understood further in the round: the kernel stays opt-in, and nothing else in the step uses that instruction form on its results.
-    static int pair_env = -1;
-    if (pair_env < 0) {
-        const char* e = getenv("GDM_KNN1_PAIR");
-        pair_env = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0;
-    }
-    const bool pair = pair_env != 0;
     KnnTable tab;
     tab.njobs = 0;
     tab.B = B;
@@ -859,18 +730,11 @@ int launch_k1(const gdm_knn_job* jobs, int njobs, int B, hipStream_t stream)
         KnnJobDev& d = tab.jobs[tab.njobs++];
         fill_job(d, jobs[i]);
         d.logT = pick_logT(d.S);
-        d.blocks_per_b = gdm_cdiv(d.Q, (pair ? 2 : 1) * (KNN_BLOCK >> d.logT));
+        d.blocks_per_b = gdm_cdiv(d.Q, KNN_BLOCK >> d.logT);
         d.block_begin = nblocks;
         nblocks += d.blocks_per_b * B;
     }
     if (tab.njobs == 0) return 0;
-    if (pair) {
-        if (pair_env == 2) hipLaunchKernelGGL(knn1_pair_kernel<1>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
-        else if (pair_env == 3) hipLaunchKernelGGL(knn1_pair_kernel<2>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
-        else if (pair_env == 4) hipLaunchKernelGGL(knn1_pair_kernel<3>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
-        else hipLaunchKernelGGL(knn1_pair_kernel<0>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
-        return gdm_launch_status("knn1_pair_kernel");
-    }
     hipLaunchKernelGGL(knn_kernel<1>, dim3(nblocks), dim3(KNN_BLOCK), 0, stream, tab);
     return gdm_launch_status("knn_kernel<1>");
 }

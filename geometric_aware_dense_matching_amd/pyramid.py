@@ -101,28 +101,20 @@ def build_pyramid(cld, dpt_xyz, overlap=False, _keep=None):
     # ~170 us earlier than behind the whole pyramid, which is what the image stream waits for at the first fusion.
     first = [i for i, nm in enumerate(names) if nm.startswith("cld_nei_idx")]
     rest = [i for i in range(len(jobs)) if i not in first]
-    import os
-    if os.environ.get("GDM_PYR_SINGLE") == "1":                 # development (tools/diag_fork_race.py): the round-2 order, one job table,
-        first, rest = [], list(range(len(jobs)))                #   K = 1 launch directly behind the first copy kernel
-        if os.environ.get("GDM_PYR_DUMMY") == "1":
-            dense[0].add_(0.0)                                   #   ... with one more kernel in between
     outs = [None] * len(jobs)
     pyr = {}
     hold = _keep if _keep is not None else []          # both workspaces live until the function returns
-    if first:
-        for i, o in zip(first, ops.knn_jobs([jobs[i] for i in first], B, keep_workspace=hold)):
-            outs[i] = o
-        pyr = dict((names[i], outs[i]) for i in first)
-        subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])     # pooling indices: prefix rows, dense
-        if _keep is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(cld.device))
-            pyr[READY_CLOUD] = ev
+    for i, o in zip(first, ops.knn_jobs([jobs[i] for i in first], B, keep_workspace=hold)):
+        outs[i] = o
+    pyr = dict((names[i], outs[i]) for i in first)
+    subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])     # pooling indices: prefix rows, dense
+    if _keep is not None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(cld.device))
+        pyr[READY_CLOUD] = ev
     for i, o in zip(rest, ops.knn_jobs([jobs[i] for i in rest], B, keep_workspace=hold)):
         outs[i] = o
     pyr.update((names[i], outs[i]) for i in rest)
-    if not first:
-        subs = ops.copy_views([pyr["cld_nei_idx%d" % i][:, : n_lv[i + 1]] for i in range(4)])
     pyr = dict([(nm, pyr[nm]) for nm in names] + [(k, v) for k, v in pyr.items() if k not in names])     # the reference's key order first
     for i in range(4):
         pyr["cld_xyz%d" % i] = levels[i]

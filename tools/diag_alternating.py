@@ -2,7 +2,7 @@
 Decides whether anything in the forked step depends on an ordering that constant-input replays cannot see (an overlap between
 consecutive replays, or a missing edge inside the graph: both are invisible when producer and consumer see the same bytes twice).
     python tools/diag_alternating.py [--rounds 40] [--burst 8] [--parts mesh,point,pyr]
-Environment (read by the library): GDM_PYR_SINGLE=1 / GDM_PYR_DUMMY=1 (round-3 launch order), GDM_KNN1_PAIR=1 (round-3 paired K = 1 kernel)."""
+(The GDM_PYR_SINGLE / GDM_PYR_DUMMY / GDM_KNN1_PAIR hooks this tool was used with in round 4 were removed with the kernel: commit 5c3353f holds them.)"""
 import argparse, collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
