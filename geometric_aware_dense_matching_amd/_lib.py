@@ -142,6 +142,9 @@ class CopyJob(ctypes.Structure):
                 ("B", ctypes.c_int32), ("R1", ctypes.c_int32), ("R2", ctypes.c_int32), ("E", ctypes.c_int32)]
 
 
+SIGNATURES["gdm_circle_match_nbr_items_hip"] = (_i, [_vp, _i, _vp, _i, _vp, _vp])
+SIGNATURES["gdm_circle_match_fwd2_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp])
+SIGNATURES["gdm_circle_match_bwd2_hip"] = (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["gdm_stem_weight_bytes"] = (_sz, [])
 SIGNATURES["gdm_stem_pack_weight_hip"] = (_i, [_vp, _vp, _vp])
 SIGNATURES["gdm_stem_hip"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp])

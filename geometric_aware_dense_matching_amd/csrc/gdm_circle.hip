@@ -134,6 +134,31 @@ __global__ __launch_bounds__(256) void cm_nbr_kernel(const float* __restrict__ x
     nbr[i] = bits;
 }
 
+// The same table PER ITEM with a per-vertex radius (geoMatch_DGCNN.py:62-70: positive_r / 1000 * z of the posed vertex):
+// nbr[b][g][w] bit k = sqrt(|xyz_g - xyz_c|^2 + 1e-7) < rad[b][c]
+__global__ __launch_bounds__(256) void cm_nbr_items_kernel(const float* __restrict__ xyz, int M, int W, const float* __restrict__ rad, int B,
+                                                           unsigned* __restrict__ nbr)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * M * W) return;
+    const int w = (int)(i % W);
+    const long bg = i / W;
+    const int g = (int)(bg % M), b = (int)(bg / M);
+    const float gx = xyz[3 * g], gy = xyz[3 * g + 1], gz = xyz[3 * g + 2];
+    const float* rb = rad + (long)b * M;
+    unsigned bits = 0;
+    for (int k = 0; k < 32; ++k) {
+        const int c = 32 * w + k;
+        if (c >= M) break;
+        const float dx = gx - xyz[3 * c], dy = gy - xyz[3 * c + 1], dz = gz - xyz[3 * c + 2];
+        float d2 = __fmul_rn(dx, dx);
+        d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+        d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+        if (__fsqrt_rn(__fadd_rn(d2, 1e-7f)) < rb[c]) bits |= 1u << k;
+    }
+    nbr[i] = bits;
+}
+
 // vis u8[B,M] (nonzero = visible) -> bits[B][W]
 __global__ __launch_bounds__(256) void cm_visbits_kernel(const unsigned char* __restrict__ vis, int B, int M, int W, unsigned* __restrict__ out)
 {
@@ -153,7 +178,7 @@ struct CmArgs {
     const unsigned char* xtp;       // scene d-major tiles
     const unsigned char* yrows;     // vertex rows, packed [Mp]
     const unsigned char* ytp;
-    const float* xsum;              // sum_d x[r][d]  (padding column)
+    const float* xsum;              // pad_e0 == 0: sum_d x[r][d] (padding column = every component -1/sqrt(128)); pad_e0: x[r][0] (column e0)
     const int32_t* g;               // [Rp] ground-truth vertex (M = none) / first positive column (symmetric)
     const int32_t* c2;              // [Rp] second positive column (symmetric) or null
     const int32_t* item;            // [Rp]
@@ -166,6 +191,8 @@ struct CmArgs {
     float* gout;                    // MODE 1: gX [Rp,128]; MODE 2: partial gY [P][Mp,128]
     int R, Rp, M, Mp, W, P;
     float gamma, m, offp, offn;
+    long nbr_istride;               // words between two items' neighbour tables (0: one table, the model's)
+    int pad_e0;                     // the padding column is the unit vector e0 (geoMatch_DGCNN.py:96-99) instead of -1/sqrt(128) everywhere
 };
 
 // word of positives of scene row (g, c2, item) inside the 32-vertex tile t
@@ -179,7 +206,7 @@ __device__ __forceinline__ unsigned pos_word(const CmArgs& a, int g, int c2, int
         return w;
     }
     if (g >= a.M || t >= a.W) return 0u;
-    return a.nbr[(long)g * a.W + t] & a.visb[(long)item * a.W + t];
+    return a.nbr[(long)item * a.nbr_istride + (long)g * a.W + t] & a.visb[(long)item * a.W + t];
 }
 
 template <int MODE, bool SYM>
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(CM_THREADS, 2) void circle_mm_kernel(const CmArgs a
     if (MODE == 0) {
         sum_p += __shfl_xor(sum_p, 32, 64);                         // lanes j and j + 32 hold the two halves of row j's columns
         sum_n += __shfl_xor(sum_n, 32, 64);
-        const float s = -a.xsum[own0 + j] * inv_sqrt_d;
+        const float s = a.pad_e0 ? a.xsum[own0 + j] : -a.xsum[own0 + j] * inv_sqrt_d;
         const bool in = SYM ? (rg == a.M || rc2 == a.M) : (rg >= a.M);
         const float av = fmaxf(in ? (1.f + mm) - s : s + mm, 0.f);
         const float dv = in ? (1.f - mm) - s : s - mm;
@@ -352,14 +379,15 @@ __global__ __launch_bounds__(CM_THREADS, 2) void circle_mm_kernel(const CmArgs a
         return;
     }
     // ---- MODE 1 / 2: outacc[db][r] = grad[owner j][d = db*32 + acc_row(r)] ----
-    float padg = 0.f;
-    if (MODE == 1) {                                                // the padding column's share: dS_pad * (-1/sqrt(128)) on every channel
-        const float s = -a.xsum[own0 + j] * inv_sqrt_d;
+    float padg = 0.f, padg0 = 0.f;                                  // added to every channel / to channel 0 only
+    if (MODE == 1) {                                                // the padding column's share: dS_pad * (-1/sqrt(128)) on every channel,
+        const float s = a.pad_e0 ? a.xsum[own0 + j] : -a.xsum[own0 + j] * inv_sqrt_d;       // or dS_pad on channel 0 (column e0)
         const bool in = SYM ? (rg == a.M || rc2 == a.M) : (rg >= a.M);
         const float av = fmaxf(in ? (1.f + mm) - s : s + mm, 0.f);
         const float dv = in ? (1.f - mm) - s : s - mm;
         const float w = __expf(av * dv * gam - (in ? rlp : rln)) * (in ? -av : av) * gam * rcoef;
-        padg = rcoef != 0.f ? -w * inv_sqrt_d : 0.f;
+        if (a.pad_e0) padg0 = rcoef != 0.f ? w : 0.f;
+        else padg = rcoef != 0.f ? -w * inv_sqrt_d : 0.f;
     }
     float* ob_out = a.gout + (MODE == 2 ? (long)part * a.Mp * 128 : 0L) + (long)(own0 + j) * 128;
 #pragma unroll
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(CM_THREADS, 2) void circle_mm_kernel(const CmArgs a
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const int d = db * 32 + 8 * q4 + 4 * h;                 // registers 4 q4 .. 4 q4 + 3 = four consecutive channels
-            *reinterpret_cast<float4*>(ob_out + d) = make_float4(outacc[db][4 * q4] + padg, outacc[db][4 * q4 + 1] + padg,
+            *reinterpret_cast<float4*>(ob_out + d) = make_float4(outacc[db][4 * q4] + padg + (d == 0 ? padg0 : 0.f), outacc[db][4 * q4 + 1] + padg,
                                                                  outacc[db][4 * q4 + 2] + padg, outacc[db][4 * q4 + 3] + padg);
         }
 }
@@ -408,6 +436,14 @@ extern "C" int gdm_circle_match_nbr_hip(const float* xyz, int M, float radius, u
     return gdm_launch_status("cm_nbr_kernel");
 }
 
+extern "C" int gdm_circle_match_nbr_items_hip(const float* xyz, int M, const float* rad, int B, uint32_t* nbr, void* stream)
+{
+    GDM_CHECK_ARG(xyz && rad && nbr && M >= 1 && B >= 1, "gdm_circle_match_nbr_items_hip: NULL pointer or M=%d B=%d", M, B);
+    const int W = (M + 31) / 32;
+    hipLaunchKernelGGL(cm_nbr_items_kernel, dim3(gdm_cdiv((long)B * M * W, 256)), dim3(256), 0, (hipStream_t)stream, xyz, M, W, rad, B, nbr);
+    return gdm_launch_status("cm_nbr_items_kernel");
+}
+
 extern "C" int gdm_circle_match_visbits_hip(const uint8_t* vis, int B, int M, uint32_t* bits, void* stream)
 {
     GDM_CHECK_ARG(vis && bits && B >= 1 && M >= 1, "gdm_circle_match_visbits_hip: NULL pointer or bad shape");
@@ -432,21 +468,32 @@ static int fill_args(CmArgs& a, const void* xrows, const void* xtp, const float*
     a.offp = 0.5f * gamma * (2.f + m) * (2.f - m);              // logits of positives span [-0.04 gamma .., gamma (2+m)(2-m)], negatives
     a.offn = 0.5f * gamma * (1.f + m) * (1.f - m);              // [.., gamma (1+m)(1-m)]: centred, exp() stays far inside fp32
     a.lse_p = a.lse_n = a.loss = nullptr; a.coef = nullptr; a.gout = nullptr;
+    a.nbr_istride = 0; a.pad_e0 = 0;
     return 0;
 }
 
 // Forward.  All per-row arrays have Rp = round_up(R, 128) entries (g = M, item = 0 for the padding rows).
+extern "C" int gdm_circle_match_fwd2_hip(const void* xrows, const void* xtp, const float* xpad, const void* yrows, const void* ytp,
+                                         int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                                         const uint32_t* nbr, int nbr_per_item, const uint32_t* visb, int pad_e0, float gamma, float m,
+                                         float* lse_p, float* lse_n, float* loss, void* stream)
+{
+    CmArgs a;
+    int rc = fill_args(a, xrows, xtp, xpad, yrows, ytp, R, M, g, c2, item, nbr, visb, gamma, m, "gdm_circle_match_fwd_hip");
+    if (rc) return rc;
+    GDM_CHECK_ARG(lse_p && lse_n && loss, "gdm_circle_match_fwd_hip: NULL output");
+    a.lse_p = lse_p; a.lse_n = lse_n; a.loss = loss;
+    a.nbr_istride = nbr_per_item ? (long)M * a.W : 0;
+    a.pad_e0 = pad_e0 ? 1 : 0;
+    return launch_mode<0>(a, c2 != nullptr, (hipStream_t)stream);
+}
+
 extern "C" int gdm_circle_match_fwd_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
                                         int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
                                         const uint32_t* nbr, const uint32_t* visb, float gamma, float m,
                                         float* lse_p, float* lse_n, float* loss, void* stream)
 {
-    CmArgs a;
-    int rc = fill_args(a, xrows, xtp, xsum, yrows, ytp, R, M, g, c2, item, nbr, visb, gamma, m, "gdm_circle_match_fwd_hip");
-    if (rc) return rc;
-    GDM_CHECK_ARG(lse_p && lse_n && loss, "gdm_circle_match_fwd_hip: NULL output");
-    a.lse_p = lse_p; a.lse_n = lse_n; a.loss = loss;
-    return launch_mode<0>(a, c2 != nullptr, (hipStream_t)stream);
+    return gdm_circle_match_fwd2_hip(xrows, xtp, xsum, yrows, ytp, R, M, g, c2, item, nbr, 0, visb, 0, gamma, m, lse_p, lse_n, loss, stream);
 }
 
 extern "C" int gdm_circle_match_bwd_parts(int R, int M)
@@ -459,14 +506,30 @@ extern "C" int gdm_circle_match_bwd_parts(int R, int M)
 }
 
 // Backward: gx f32[Rp,128] and gy_part f32[P][Mp,128] (P = gdm_circle_match_bwd_parts; the caller sums over P).
+extern "C" int gdm_circle_match_bwd2_hip(const void* xrows, const void* xtp, const float* xpad, const void* yrows, const void* ytp,
+                                         int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                                         const uint32_t* nbr, int nbr_per_item, const uint32_t* visb, int pad_e0, float gamma, float m,
+                                         const float* lse_p, const float* lse_n, const float* coef, float* gx, float* gy_part, void* stream);
+
 extern "C" int gdm_circle_match_bwd_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
                                         int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
                                         const uint32_t* nbr, const uint32_t* visb, float gamma, float m,
                                         const float* lse_p, const float* lse_n, const float* coef, float* gx, float* gy_part, void* stream)
 {
+    return gdm_circle_match_bwd2_hip(xrows, xtp, xsum, yrows, ytp, R, M, g, c2, item, nbr, 0, visb, 0, gamma, m, lse_p, lse_n, coef, gx, gy_part,
+                                     stream);
+}
+
+extern "C" int gdm_circle_match_bwd2_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
+                                         int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                                         const uint32_t* nbr, int nbr_per_item, const uint32_t* visb, int pad_e0, float gamma, float m,
+                                         const float* lse_p, const float* lse_n, const float* coef, float* gx, float* gy_part, void* stream)
+{
     CmArgs a;
     int rc = fill_args(a, xrows, xtp, xsum, yrows, ytp, R, M, g, c2, item, nbr, visb, gamma, m, "gdm_circle_match_bwd_hip");
     if (rc) return rc;
+    a.nbr_istride = nbr_per_item ? (long)M * a.W : 0;
+    a.pad_e0 = pad_e0 ? 1 : 0;
     GDM_CHECK_ARG(lse_p && lse_n && coef && gx && gy_part, "gdm_circle_match_bwd_hip: NULL pointer");
     a.lse_p = const_cast<float*>(lse_p); a.lse_n = const_cast<float*>(lse_n); a.coef = coef;
     a.gout = gx;

@@ -694,6 +694,267 @@ __global__ __launch_bounds__(KW_BLOCK) void knn_grid_kernel(const KnnTable tab)
     }
 }
 
+// ---- K > 1, large unorganised support: uniform (x, y) cell lists ---------------------------------------------------------------
+// The cloud's own K = 16 search (2048 x 2048 per crop, linemod_pbr.py:535) was the one search left that evaluated every pair: ~110
+// admitted candidates and 3-4 sorts per query on top of 32 scan steps.  Here the support of a crop is binned ONCE into G x G cells (kc_grid)
+// of its (x, y) bounding box (knn_cells_bin_kernel: counting sort in LDS, one workgroup per crop) and a query visits the cells ring
+// by ring around its own -- 3 x 3 first, one wave step per cell row -- until the nearest edge of the visited window lies farther than
+// the current K-th distance: dx (or dy) alone already exceeds it for every unvisited point.  Exact for any data (same (d2, index)
+// keys, the window just grows to the whole grid in the worst case); the bound carries a 0.1 % allowance on d2 for the rounding of the
+// cell assignment.
+constexpr int KC_MIN_S = 1024;          // supports below this stay on knn_wave_kernel
+constexpr int KC_GMAX = 32;             // cells per axis: 16 below 8192 points, 32 from there (kc_grid).  Measured on the pyramid's 2048-point clouds
+                                        // (tools/knn_cells_stats.py): 16 -> 1.8 rings, 2.6 row batches, 2.7 sorts per query, 64 us per batch of
+                                        // 16 crops; 32 -> 2.2 rings, 4.9 row batches, 2.5 sorts, 99 us: the row batches (L2 round trips), not the
+                                        // distance evaluations, are what a query pays for
+constexpr int KC_CELLS_MAX = KC_GMAX * KC_GMAX;
+constexpr int KC_FOFF = (KC_CELLS_MAX + 1 + 3) & ~3;     // words per crop: cell_start[G * G + 1], then at KC_FOFF xmin, ymin, cw, ch, 1/cw, 1/ch, -, -
+constexpr int KC_META = KC_FOFF + 8;
+constexpr int KC_BIN_THREADS = 1024;
+__host__ __device__ inline int kc_grid(int S) { return S >= 8192 ? 32 : 16; }
+
+struct CellEntry {
+    const float* support;
+    float4* sorted;                     // [B][S]: (x, y, z, index) in cell order
+    int* meta;                          // [B][KC_META]
+    long long support_bstride;
+    int S;
+};
+
+struct CellTable {
+    CellEntry e[GDM_KNN_MAX_JOBS];
+    int n;
+    int B;
+};
+
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv, int G)
+{
+    const float f = (v - lo) * inv;                      // NaN / -inf compare false -> cell 0; +inf -> the last cell
+    return f >= 0.f ? (f < (float)G ? (int)f : G - 1) : 0;
+}
+
+__global__ __launch_bounds__(KC_BIN_THREADS) void knn_cells_bin_kernel(const CellTable tab)
+{
+    __shared__ float red[4][KC_BIN_THREADS / 64];
+    __shared__ int cnt[KC_CELLS_MAX], cur[KC_CELLS_MAX];
+    __shared__ float box[4];
+    const int ei = blockIdx.x / tab.B, b = blockIdx.x - ei * tab.B;
+    const CellEntry& e = tab.e[ei];
+    const int S = e.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = kc_grid(S), cells = G * G;
+    const float* sup = e.support + (long long)b * e.support_bstride;
+    float4* sorted = e.sorted + (long long)b * S;
+    int* meta = e.meta + (long long)b * KC_META;
+    // 1. bounding box of the finite (x, y)
+    float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (int p = tid; p < S; p += KC_BIN_THREADS) {
+        const float x = sup[(long long)p * 3], y = sup[(long long)p * 3 + 1];
+        if (isfinite(x)) { xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); }
+        if (isfinite(y)) { ylo = fminf(ylo, y); yhi = fmaxf(yhi, y); }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        xlo = fminf(xlo, __shfl_xor(xlo, m, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, m, 64));
+        ylo = fminf(ylo, __shfl_xor(ylo, m, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, m, 64));
+    }
+    if (lane == 0) { red[0][wave] = xlo; red[1][wave] = xhi; red[2][wave] = ylo; red[3][wave] = yhi; }
+    if (tid < cells) cnt[tid] = 0;                     // cells <= KC_BIN_THREADS
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < KC_BIN_THREADS / 64; ++w) {
+            xlo = fminf(xlo, red[0][w]); xhi = fmaxf(xhi, red[1][w]); ylo = fminf(ylo, red[2][w]); yhi = fmaxf(yhi, red[3][w]);
+        }
+        if (!(xhi >= xlo)) xlo = xhi = 0.f;              // no finite coordinate at all
+        if (!(yhi >= ylo)) ylo = yhi = 0.f;
+        const float cw = (xhi - xlo) / (float)G, ch = (yhi - ylo) / (float)G;
+        box[0] = xlo; box[1] = ylo;
+        box[2] = cw > 0.f ? 1.f / cw : 0.f;              // a degenerate axis puts everything into its cell 0
+        box[3] = ch > 0.f ? 1.f / ch : 0.f;
+        float* fm = reinterpret_cast<float*>(meta + KC_FOFF);
+        fm[0] = xlo; fm[1] = ylo; fm[2] = cw; fm[3] = ch; fm[4] = box[2]; fm[5] = box[3]; fm[6] = 0.f; fm[7] = 0.f;
+    }
+    __syncthreads();
+    const float bx0 = box[0], by0 = box[1], icw = box[2], ich = box[3];
+    // 2. histogram, 3. exclusive scan, 4. scatter (order inside a cell is arbitrary: the search orders candidates by (d2, index) keys)
+    for (int p = tid; p < S; p += KC_BIN_THREADS) {
+        const int c = cell_coord(sup[(long long)p * 3 + 1], by0, ich, G) * G + cell_coord(sup[(long long)p * 3], bx0, icw, G);
+        atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {                                      // wave 0: cells / 64 consecutive cells per lane, shuffle scan of the lane sums
+        const int per = cells / 64;
+        int sum = 0;
+        for (int i = 0; i < per; ++i) sum += cnt[tid * per + i];
+        int inc = sum;
+        for (int m = 1; m < 64; m <<= 1) {
+            const int o = __shfl_up(inc, m, 64);
+            if (lane >= m) inc += o;
+        }
+        int run = inc - sum;
+        for (int i = 0; i < per; ++i) {
+            const int c = tid * per + i, v = cnt[c];
+            cur[c] = run;
+            meta[c] = run;
+            run += v;
+        }
+        if (tid == 63) meta[cells] = run;                // == S
+    }
+    __syncthreads();
+    for (int p = tid; p < S; p += KC_BIN_THREADS) {
+        const float x = sup[(long long)p * 3], y = sup[(long long)p * 3 + 1], z = sup[(long long)p * 3 + 2];
+        const int c = cell_coord(y, by0, ich, G) * G + cell_coord(x, bx0, icw, G);
+        const int pos = atomicAdd(&cur[c], 1);
+        sorted[pos] = make_float4(x, y, z, __int_as_float(p));
+    }
+}
+
+#ifdef GDM_KNN_STATS
+__device__ unsigned long long gdm_knn_stats_dev[8];      // queries, rings, row batches, extra steps, compactions, admitted, -, -
+#define KSTAT(i, v) do { if (lane == 0) atomicAdd(&gdm_knn_stats_dev[i], (unsigned long long)(v)); } while (0)
+#else
+#define KSTAT(i, v) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(KW_BLOCK) void knn_cells_kernel(const KnnTable tab)
+{
+    __shared__ int cstart[KC_CELLS_MAX + 1];
+    __shared__ u64 cand[KW_WAVES][64];
+
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < tab.njobs && bid >= tab.jobs[j + 1].block_begin) ++j;
+    const KnnJobDev& job = tab.jobs[j];
+    const int local = bid - job.block_begin;
+    const int b = local / job.blocks_per_b;
+    const int qb = local - b * job.blocks_per_b;
+    const int S = job.S, Q = job.Q, K = job.K;
+    const int G = kc_grid(S);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int* meta = reinterpret_cast<const int*>(job.ranges) + (long long)b * KC_META;
+    const float4* sorted = job.packed + (long long)b * S;
+    for (int i = tid; i <= G * G; i += KW_BLOCK) cstart[i] = meta[i];
+    __syncthreads();
+    const int q = qb * KW_WAVES + wave;
+    if (q >= Q) return;                                  // wave-uniform; no barrier below
+    const float* fm = reinterpret_cast<const float*>(meta + KC_FOFF);
+    const float bx0 = fm[0], by0 = fm[1], cw = fm[2], ch = fm[3], icw = fm[4], ich = fm[5];
+    const float* qry = job.query + (long long)b * job.query_bstride + (long long)q * 3;
+    const float qx = qry[0], qy = qry[1], qz = qry[2];
+    u64* buf = cand[wave];
+
+    float td = INFINITY;
+    int ti = IDX_EMPTY;
+    int cnt = 0;
+    auto compact = [&]() -> u64 {
+        KSTAT(4, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        u64 key = lane < cnt ? buf[lane] : KEY_EMPTY;
+        wave_sort64(key, lane);
+        if (lane < K) buf[lane] = key;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cnt = min(cnt, K);
+        td = __int_as_float(__shfl((int)(unsigned)(key >> 32), K - 1, 64));
+        ti = __shfl((int)(unsigned)key, K - 1, 64);
+        return key;
+    };
+    auto admit = [&](float d, int di) {
+        if (__ballot(d <= td) == 0ull) return;
+        bool pass = lex_less(d, di, td, ti);
+        unsigned long long bal = __ballot(pass);
+        while (bal) {
+            const int n = __builtin_popcountll(bal);
+            if (cnt + n > 64 && cnt > K) {
+                compact();
+                pass = pass && lex_less(d, di, td, ti);
+                bal = __ballot(pass);
+                continue;
+            }
+            const int room = 64 - cnt;
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            const bool now = pass && pos < room;
+            if (now) buf[cnt + pos] = make_key(d, di);
+            cnt += min(n, room);
+            pass = pass && !now;
+            bal = __ballot(pass);
+        }
+    };
+    // Rows of the window, FOUR at a time: a row's new cells are sorted[l0, l1) and sorted[r0, r1) (its two flanks, or its whole width);
+    // the first 64 points of each of the four rows are loaded together (four independent L2 round trips in flight instead of one
+    // after the other -- the search is latency-bound), then admitted row by row; a row with more than 64 new points continues alone.
+    auto rows4 = [&](int y0, int ny1, int nx0, int nx1, int ox0, int ox1, int oy0, int oy1) {
+        int l0[4], nl[4], r0[4], tot[4];
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = y0 + i;
+            l0[i] = nl[i] = r0[i] = tot[i] = 0;
+            if (y <= ny1) {
+                const int row = y * G;
+                if (y < oy0 || y > oy1) {                             // a new row: whole width
+                    l0[i] = cstart[row + nx0];
+                    nl[i] = cstart[row + nx1 + 1] - l0[i];
+                    tot[i] = nl[i];
+                } else {                                              // an old row: the two new flanks
+                    l0[i] = cstart[row + nx0];
+                    nl[i] = cstart[row + ox0] - l0[i];
+                    r0[i] = cstart[row + ox1 + 1];
+                    tot[i] = nl[i] + cstart[row + nx1 + 1] - r0[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pos = lane < tot[i] ? (lane < nl[i] ? l0[i] + lane : r0[i] + (lane - nl[i])) : 0;
+            v[i] = sorted[pos];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool live = lane < tot[i];
+            admit(live ? dist2_ref(qx, qy, qz, v[i].x, v[i].y, v[i].z) : INFINITY, live ? __float_as_int(v[i].w) : IDX_EMPTY);
+            for (int e0 = 64; e0 < tot[i]; e0 += 64) {
+                KSTAT(3, 1);
+                const int e = e0 + lane;
+                const bool lv = e < tot[i];
+                const float4 w = sorted[lv ? (e < nl[i] ? l0[i] + e : r0[i] + (e - nl[i])) : 0];
+                admit(lv ? dist2_ref(qx, qy, qz, w.x, w.y, w.z) : INFINITY, lv ? __float_as_int(w.w) : IDX_EMPTY);
+            }
+        }
+    };
+
+    const int qcx = cell_coord(qx, bx0, icw, G), qcy = cell_coord(qy, by0, ich, G);
+    int ox0 = qcx, ox1 = qcx - 1, oy0 = qcy, oy1 = qcy - 1;          // visited window: empty
+    int r = 1;
+    u64 key = KEY_EMPTY;
+    KSTAT(0, 1);
+    while (true) {
+        KSTAT(1, 1);
+        const int nx0 = max(qcx - r, 0), nx1 = min(qcx + r, G - 1), ny0 = max(qcy - r, 0), ny1 = min(qcy + r, G - 1);
+        for (int y = ny0; y <= ny1; y += 4) { KSTAT(2, 1); rows4(y, ny1, nx0, nx1, ox0, ox1, oy0, oy1); }
+        key = compact();
+        ox0 = nx0; ox1 = nx1; oy0 = ny0; oy1 = ny1;
+        if (nx0 == 0 && nx1 == G - 1 && ny0 == 0 && ny1 == G - 1) break;                 // the whole grid
+        // distance from the query to the nearest edge of the window that still has cells beyond it
+        const float exl = nx0 == 0 ? INFINITY : qx - (bx0 + (float)nx0 * cw);
+        const float exh = nx1 == G - 1 ? INFINITY : (bx0 + (float)(nx1 + 1) * cw) - qx;
+        const float eyl = ny0 == 0 ? INFINITY : qy - (by0 + (float)ny0 * ch);
+        const float eyh = ny1 == G - 1 ? INFINITY : (by0 + (float)(ny1 + 1) * ch) - qy;
+        const float m = fminf(fminf(exl, exh), fminf(eyl, eyh));
+        if (m > 0.f && m * m * 0.999f > td) break;                                       // (td = inf while fewer than K are known)
+        // next ring: far enough for the current K-th distance where it is known, else twice as far
+        const float cmin = fminf(cw > 0.f ? cw : INFINITY, ch > 0.f ? ch : INFINITY);
+        int want = r * 2;
+        if (td < INFINITY && cmin < INFINITY) want = (int)fminf((float)G, ceilf(sqrtf(td) / cmin)) + 1;
+        r = min(G, max(r + 1, want));
+    }
+    if (lane < K) {
+        const long long o = ((long long)b * Q + q) * K + lane;
+        const int si = (int)(unsigned)key;
+        const float sd = __int_as_float((int)(unsigned)(key >> 32));
+        job.idx[o] = si == IDX_EMPTY ? 0 : si;
+        if (job.d2) job.d2[o] = isinf(sd) ? 3.402823466e+38f : sd;
+    }
+}
+
 int pick_logT(int S)
 {
     // every lane scans >= 128 support points where possible; T in {1,2,...,64}
@@ -754,6 +1015,10 @@ bool is_grid_job(const gdm_knn_job& j)
 
 size_t ranges_bytes(const gdm_knn_job& j, int B) { return (size_t)B * range_floats(j.grid_w, j.S / j.grid_w) * sizeof(float); }
 
+// a large unorganised support: cell lists (knn_cells_bin_kernel + knn_cells_kernel)
+bool is_cell_job(const gdm_knn_job& j) { return j.K > 1 && !is_grid_job(j) && j.S >= KC_MIN_S; }
+size_t cells_bytes(int S, int B) { return (size_t)B * S * sizeof(float4) + (((size_t)B * KC_META * sizeof(int) + 15) & ~(size_t)15); }
+
 bool same_support(const gdm_knn_job& a, const gdm_knn_job& b)
 {
     return a.support == b.support && a.S == b.S && a.support_bstride == b.support_bstride;
@@ -764,9 +1029,14 @@ bool same_support(const gdm_knn_job& a, const gdm_knn_job& b)
 // it, and the searches against organised supports (grid_w > 0) run as window searches (knn_grid_ranges_kernel + knn_grid_kernel).
 int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    KnnTable tab, gtab;
-    tab.njobs = gtab.njobs = 0;
-    tab.B = gtab.B = B;
+    KnnTable tab, gtab, ctab;                            // wave / organised / cell lists
+    tab.njobs = gtab.njobs = ctab.njobs = 0;
+    tab.B = gtab.B = ctab.B = B;
+    CellTable ct;
+    ct.n = 0;
+    ct.B = B;
+    const gdm_knn_job* ct_job[GDM_KNN_MAX_JOBS];
+    int cblocks = 0;
     int order[GDM_KNN_MAX_JOBS], n = 0;
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].K > 1) order[n++] = i;
@@ -823,6 +1093,39 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
                 continue;
             }
         }
+        if (workspace && is_cell_job(jb)) {               // large unorganised support: cell lists
+            int e = 0;
+            while (e < ct.n && !same_support(*ct_job[e], jb)) ++e;
+            bool ok = e < ct.n;
+            if (!ok) {
+                const size_t need = cells_bytes(jb.S, B);
+                if (used + need <= workspace_bytes) {
+                    CellEntry& ce = ct.e[ct.n];
+                    ce.support = jb.support;
+                    ce.support_bstride = jb.support_bstride;
+                    ce.S = jb.S;
+                    ce.sorted = (float4*)((char*)workspace + used);
+                    ce.meta = (int*)((char*)workspace + used + (size_t)B * jb.S * sizeof(float4));
+                    ct_job[ct.n++] = &jb;
+                    used += need;
+                    ok = true;
+                }
+            }
+            if (ok) {
+                KnnTable& tt = ctab;
+                int& nb = cblocks;
+                KnnJobDev& d = tt.jobs[tt.njobs++];
+                fill_job(d, jb);
+                d.logT = 0;
+                d.packed = ct.e[e].sorted;
+                d.ranges = reinterpret_cast<const float*>(ct.e[e].meta);
+                d.grid_w = kc_grid(jb.S);
+                d.blocks_per_b = gdm_cdiv(d.Q, KW_WAVES);
+                d.block_begin = nb;
+                nb += d.blocks_per_b * B;
+                continue;
+            }
+        }
         KnnJobDev& d = tab.jobs[tab.njobs++];
         fill_job(d, jb);
         d.logT = 0;
@@ -854,9 +1157,17 @@ int launch_wave(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size
         hipLaunchKernelGGL(knn_grid_ranges_kernel, dim3(range_blocks), dim3(256), 0, stream, rt);
         if ((rc = gdm_launch_status("knn_grid_ranges_kernel"))) return rc;
     }
+    if (ct.n) {
+        hipLaunchKernelGGL(knn_cells_bin_kernel, dim3(ct.n * B), dim3(KC_BIN_THREADS), 0, stream, ct);
+        if ((rc = gdm_launch_status("knn_cells_bin_kernel"))) return rc;
+    }
     if (pk.n) {
         hipLaunchKernelGGL(knn_pack_kernel, dim3(pack_blocks), dim3(256), 0, stream, pk);
         if ((rc = gdm_launch_status("knn_pack_kernel"))) return rc;
+    }
+    if (ctab.njobs) {
+        hipLaunchKernelGGL(knn_cells_kernel, dim3(cblocks), dim3(KW_BLOCK), 0, stream, ctab);
+        if ((rc = gdm_launch_status("knn_cells_kernel"))) return rc;
     }
     if (tab.njobs) {
         hipLaunchKernelGGL(knn_wave_kernel, dim3(nblocks), dim3(KW_BLOCK), 0, stream, tab);
@@ -886,6 +1197,18 @@ static int check_jobs(const gdm_knn_job* jobs, int njobs, int B, const char* who
     return 0;
 }
 
+#ifdef GDM_KNN_STATS
+extern "C" int gdm_knn_stats_read(unsigned long long* out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gdm_knn_stats_dev), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gdm_knn_stats_dev), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 extern "C" size_t gdm_knn_jobs_workspace_bytes(const gdm_knn_job* jobs, int njobs, int B)
 {
     if (!jobs || njobs < 0 || njobs > GDM_KNN_MAX_JOBS || B < 1) return 0;
@@ -896,7 +1219,9 @@ extern "C" size_t gdm_knn_jobs_workspace_bytes(const gdm_knn_job* jobs, int njob
         for (int e = 0; e < i && !seen; ++e)
             seen = jobs[e].K > 1 && same_support(jobs[e], jobs[i]) && is_grid_job(jobs[e]) == is_grid_job(jobs[i]);
         if (seen) continue;
-        total += is_grid_job(jobs[i]) ? ((ranges_bytes(jobs[i], B) + 15) & ~(size_t)15) : packed_bytes(jobs[i].S, B);
+        // (a cell job is sized for both layouts: it falls back to the hashed tiles when the cell lists no longer fit)
+        total += is_grid_job(jobs[i]) ? ((ranges_bytes(jobs[i], B) + 15) & ~(size_t)15)
+                                      : (is_cell_job(jobs[i]) ? cells_bytes(jobs[i].S, B) : packed_bytes(jobs[i].S, B));
     }
     return total;
 }

@@ -7,7 +7,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .dgcnn import DgcnnMeshEmb, DgcnnPcdEmb
-from .geoMatch import pdist
 from .layers import PtSeq, pt_conv1d
 from .loss import AutomaticWeightedLoss, CircleLoss, FocalLoss
 
@@ -30,48 +29,40 @@ class GeoMatch(nn.Module):
                                        .conv1d(self.feat_dim, activation=None, bias=False))
         self.normalize_feature_layer = pt_conv1d(self.feat_dim, self.feat_dim, bn=True)
 
-    def matching_loss(self, similarity, match_idx, mesh_xyz, vis_flag, RT):
-        n_node = len(mesh_xyz)
-        dev = similarity.device
-        idx_in_mesh = match_idx != n_node
-        idx_mesh_in = torch.where(idx_in_mesh)[0]
-        idx_out_mesh = match_idx == n_node
-        vis = vis_flag.to(torch.bool)
-        gt_pt = mesh_xyz[match_idx[idx_in_mesh]]
-        valid_vis_pts = mesh_xyz[vis]
-        dis_matrix = pdist(gt_pt, valid_vis_pts)
-        proj = torch.matmul(valid_vis_pts, RT[:, :3].t()) + RT[:, 3:].t()
-        positive_radius = self.positive_r / 1000.0 * proj[:, 2]                 # geoMatch_DGCNN.py:66-67
-        pts_num, cols = similarity.shape
-        p_n_mask = torch.zeros((pts_num, cols - 1), dtype=torch.bool, device=dev)
-        p_n_in_mesh = torch.index_select(p_n_mask, 0, idx_mesh_in)
-        p_n_in_mesh[:, vis] = dis_matrix < positive_radius
-        p_n_mask[idx_in_mesh] = p_n_in_mesh
-        p_n_mask = torch.cat([p_n_mask, idx_out_mesh.unsqueeze(1)], dim=1)
-        return self.circle_loss(similarity, p_n_mask, 0.2)
-
     def pointwise_feature_matching(self, rgbd_feature, mesh_feature, x):
-        """geoMatch_DGCNN.py:80-135: all points normalised, similarity for the whole batch in one matmul, the
-        padding column is the unit vector e0 (not -1 as in the FFB6D variant), rows picked by `origin_labels`."""
-        losses = []
-        batch = rgbd_feature.shape[0]
-        rgbd_feature = F.normalize(rgbd_feature.transpose(1, 2), p=2, dim=2)
+        """The training matching loss of geoMatch_DGCNN.py:52-135 for the whole batch at once, WITHOUT the [B, N, M+1] similarity:
+        value and gradients of the reference's per-item loop (mean over the items with >= 3 rows of `origin_labels == 1` of the
+        mean circle loss of their rows).  What differs from the FFB6D variant (geoMatch.GeoMatch.pointwise_feature_matching):
+          * the padding column is the unit vector e0 (:96-99): its similarity with a row is the row's first component;
+          * a vertex v is a positive of a row with ground-truth vertex g when it is visible in the row's item and
+            pdist(g, v) < positive_r / 1000 * z_i(v), z_i(v) = depth of v posed by the item's RT (:62-67): the radius depends on the
+            item AND the vertex, so the positive tables are built per item (ops.circle_nbr_items, one launch for the batch) and the
+            fused kernels index them by (item, g) -- ops.circle_match(..., pad="e0")."""
+        from . import ops
+        if not rgbd_feature.is_cuda:
+            raise RuntimeError("GeoMatch (DGCNN) training matching loss runs on the GPU (HIP kernels); there is no CPU fallback")
+        B, D, N = rgbd_feature.shape
         mesh = mesh_feature[0]
-        padding = torch.zeros((self.feat_dim, 1), dtype=torch.float32, device=mesh.device)
-        padding[0] = 1
-        mesh_padded = F.normalize(torch.cat([mesh, padding], dim=1), p=2, dim=0)
-        sim = torch.matmul(rgbd_feature, mesh_padded)
-        labels, corr, RTs = x["origin_labels"], x["match_idx"], x["RT"]
-        mesh_xyz = self.model_emb.mesh[0][:3, :].transpose(0, 1).contiguous()
-        for i in range(batch):
-            idxs = torch.where(labels[i] == 1)[0]
-            if len(idxs) < 3:
-                continue
-            losses.append(self.matching_loss(sim[i][idxs, :], corr[i].index_select(0, idxs).long(), mesh_xyz,
-                                             x["visible_flag"][i], RTs[i]))
-        if not losses:
+        M = mesh.shape[1]
+        sel = x["origin_labels"] == 1
+        counts = sel.sum(dim=1)
+        item_ok = counts >= 3                                      # :112-113
+        sel = sel & item_ok.unsqueeze(1)
+        bi, pi = torch.nonzero(sel, as_tuple=True)                 # row-major: item, then point order
+        if bi.numel() == 0:
             return torch.zeros((), device=mesh.device)
-        return torch.mean(torch.stack(losses))
+        rows = F.normalize(rgbd_feature.transpose(1, 2)[bi, pi], p=2, dim=1)          # [R,128] (normalising a row commutes with selecting it)
+        mesh_rows = F.normalize(mesh, p=2, dim=0).t().contiguous()                   # [M,128]; the padding column stays e0 under the normalisation
+        g = x["match_idx"].long()[bi, pi]
+        mesh_xyz = self.model_emb.mesh[0][:3, :].transpose(0, 1).contiguous()         # [M,3]
+        RT = x["RT"].to(mesh_xyz.dtype)
+        z = torch.matmul(mesh_xyz, RT[:, 2, :3].unsqueeze(2)).squeeze(2) + RT[:, 2, 3:4]     # [B,M]: third row of RT . v (:65)
+        rad = (self.positive_r / 1000.0 * z).contiguous()
+        lrow = ops.circle_match(rows, mesh_rows, g, bi, nbr=ops.circle_nbr_items(mesh_xyz, rad),
+                                visb=ops.circle_visbits(x["visible_flag"]), gamma=16.0, m=0.2, pad="e0")
+        per_item = torch.zeros(B, dtype=torch.float32, device=mesh.device).index_add_(0, bi, lrow)
+        per_item = per_item[item_ok] / counts[item_ok].to(torch.float32)
+        return per_item.mean()
 
     def forward(self, inputs, end_points=None):
         if not end_points:

@@ -491,6 +491,19 @@ def circle_nbr_table(xyz, radius):
     return nbr
 
 
+def circle_nbr_items(xyz, rad):
+    """Per-item positive tables u32[B, M, ceil(M/32)] for a per-item, per-vertex radius rad f32[B,M]: bit c of row (b, g) =
+    sqrt(|xyz_g - xyz_c|^2 + 1e-7) < rad[b, c] (the geoMatch_DGCNN variant, geoMatch_DGCNN.py:62-70)."""
+    xyz = _dev(xyz, torch.float32, "xyz")
+    rad = _dev(rad, torch.float32, "rad")
+    B, M = rad.shape
+    assert xyz.shape == (M, 3)
+    nbr = torch.empty((B, M, (M + 31) // 32), dtype=torch.int32, device=xyz.device)
+    check(_lib.lib().gdm_circle_match_nbr_items_hip(xyz.data_ptr(), M, rad.data_ptr(), B, nbr.data_ptr(), _stream()),
+          "gdm_circle_match_nbr_items_hip")
+    return nbr
+
+
 def circle_visbits(vis):
     """visible_flag (any dtype, nonzero = visible) [B,M] -> bits i32[B, ceil(M/32)]."""
     if not vis.is_cuda:
@@ -523,7 +536,7 @@ def _pad_rows(t, npad, fill):
 
 class _CircleMatch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, g, c2, item, nbr, visb, gamma, m):
+    def forward(ctx, x, y, g, c2, item, nbr, visb, gamma, m, pad_e0=False):
         x = _dev(x, torch.float32, "x")
         y = _dev(y, torch.float32, "y")
         R, M = x.shape[0], y.shape[0]
@@ -531,24 +544,28 @@ class _CircleMatch(torch.autograd.Function):
         Rp = (R + 127) // 128 * 128
         xr, xt, xs = _cm_pack(x)
         yr, yt, _ = _cm_pack(y)
+        per_item = nbr is not None and nbr.dim() == 3            # [B, M, W]: one table per batch item (circle_nbr_items)
+        if pad_e0:
+            xs = _pad_rows(x[:, 0].contiguous(), Rp, 0.0)          # <x_r, e0>: the similarity with the padding column
         gp = _pad_rows(g, Rp, M)
         ip = _pad_rows(item, Rp, 0)
         c2p = _pad_rows(c2, Rp, -1) if c2 is not None else None
         lp = torch.empty(Rp, dtype=torch.float32, device=x.device)
         ln = torch.empty_like(lp)
         loss = torch.empty_like(lp)
-        check(_lib.lib().gdm_circle_match_fwd_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M,
-                                                  gp.data_ptr(), c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
-                                                  nbr.data_ptr() if nbr is not None else None, visb.data_ptr() if visb is not None else None,
-                                                  gamma, m, lp.data_ptr(), ln.data_ptr(), loss.data_ptr(), _stream()), "gdm_circle_match_fwd_hip")
+        check(_lib.lib().gdm_circle_match_fwd2_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M,
+                                                   gp.data_ptr(), c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
+                                                   nbr.data_ptr() if nbr is not None else None, int(per_item),
+                                                   visb.data_ptr() if visb is not None else None, int(bool(pad_e0)),
+                                                   gamma, m, lp.data_ptr(), ln.data_ptr(), loss.data_ptr(), _stream()), "gdm_circle_match_fwd_hip")
         ctx.save_for_backward(xr, xt, xs, yr, yt, gp, ip, lp, ln)
-        ctx.extra = (c2p, nbr, visb, gamma, m, R, M)
+        ctx.extra = (c2p, nbr, visb, gamma, m, R, M, per_item, bool(pad_e0))
         return loss[:R]
 
     @staticmethod
     def backward(ctx, gout):
         xr, xt, xs, yr, yt, gp, ip, lp, ln = ctx.saved_tensors
-        c2p, nbr, visb, gamma, m, R, M = ctx.extra
+        c2p, nbr, visb, gamma, m, R, M, per_item, pad_e0 = ctx.extra
         L = _lib.lib()
         Rp, Mp = lp.shape[0], (M + 127) // 128 * 128
         z = lp[:R] + ln[:R]
@@ -558,26 +575,31 @@ class _CircleMatch(torch.autograd.Function):
         P = int(L.gdm_circle_match_bwd_parts(R, M))
         gx = torch.empty((Rp, 128), dtype=torch.float32, device=lp.device)
         gyp = torch.empty((P, Mp, 128), dtype=torch.float32, device=lp.device)
-        check(L.gdm_circle_match_bwd_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M, gp.data_ptr(),
-                                         c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
-                                         nbr.data_ptr() if nbr is not None else None, visb.data_ptr() if visb is not None else None,
-                                         gamma, m, lp.data_ptr(), ln.data_ptr(), coef.data_ptr(), gx.data_ptr(), gyp.data_ptr(), _stream()),
+        check(L.gdm_circle_match_bwd2_hip(xr.data_ptr(), xt.data_ptr(), xs.data_ptr(), yr.data_ptr(), yt.data_ptr(), R, M, gp.data_ptr(),
+                                          c2p.data_ptr() if c2p is not None else None, ip.data_ptr(),
+                                          nbr.data_ptr() if nbr is not None else None, int(per_item),
+                                          visb.data_ptr() if visb is not None else None, int(pad_e0),
+                                          gamma, m, lp.data_ptr(), ln.data_ptr(), coef.data_ptr(), gx.data_ptr(), gyp.data_ptr(), _stream()),
               "gdm_circle_match_bwd_hip")
-        return gx[:R], gyp.sum(dim=0)[:M], None, None, None, None, None, None, None
+        return gx[:R], gyp.sum(dim=0)[:M], None, None, None, None, None, None, None, None
 
 
-def circle_match(x, y, g, item, nbr=None, visb=None, c2=None, gamma=16.0, m=0.2):
+def circle_match(x, y, g, item, nbr=None, visb=None, c2=None, gamma=16.0, m=0.2, pad="ones"):
     """Per-row circle loss of unit scene rows x f32[R,128] against unit vertex rows y f32[M,128] WITHOUT the [R, M+1] similarity
     matrix (geoMatch.py:117-136 + :55-100 + loss.py:441-494, forward and backward).  g int[R]: ground-truth vertex (M = none),
     item int[R]: batch item; positives from `nbr` (circle_nbr_table) & `visb` (circle_visbits), or -- symmetric objects -- the two
-    columns g / c2 of each row.  Returns f32[R]; differentiable w.r.t. x and y."""
+    columns g / c2 of each row.  `nbr` may be one table per batch item (circle_nbr_items, [B, M, W]); pad = "ones": the padding column
+    is -1/sqrt(128) everywhere (geoMatch.py:117-119), "e0": the unit vector e0 (geoMatch_DGCNN.py:96-99).  Returns f32[R];
+    differentiable w.r.t. x and y."""
+    if pad not in ("ones", "e0"):
+        raise ValueError("circle_match: pad=%r" % (pad,))
     g = _idx32(g, "g")
     item = _idx32(item, "item")
     if c2 is not None:
         c2 = _idx32(c2, "c2")
     elif nbr is None or visb is None:
         raise ValueError("circle_match: pass nbr and visb (radius-test positives) or c2 (symmetric objects)")
-    return _CircleMatch.apply(x, y, g, c2, item, nbr, visb, float(gamma), float(m))
+    return _CircleMatch.apply(x, y, g, c2, item, nbr, visb, float(gamma), float(m), pad == "e0")
 
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2

@@ -277,6 +277,19 @@ int gdm_circle_match_fwd_hip(const void* xrows, const void* xtp, const float* xs
                              int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
                              const uint32_t* nbr, const uint32_t* visb, float gamma, float m,
                              float* lse_p, float* lse_n, float* loss, void* stream);
+/* The same two kernels for the geoMatch_DGCNN variant (/root/reference/models/geoMatch_DGCNN.py:52-135): nbr_per_item != 0 -- `nbr` holds one
+ * neighbour table PER BATCH ITEM, u32[B][M][ceil(M/32)] made by gdm_circle_match_nbr_items_hip from a per-item, per-vertex radius
+ * (positive_r / 1000 * z of the posed vertex, :66-67); pad_e0 != 0 -- the padding column is the unit vector e0 (:96-99) and `xpad`
+ * holds x[r][0] instead of the row sums.  (0, 0) = gdm_circle_match_fwd_hip / _bwd_hip.                                            */
+int gdm_circle_match_nbr_items_hip(const float* xyz, int M, const float* rad /* f32[B,M] */, int B, uint32_t* nbr, void* stream);
+int gdm_circle_match_fwd2_hip(const void* xrows, const void* xtp, const float* xpad, const void* yrows, const void* ytp,
+                              int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                              const uint32_t* nbr, int nbr_per_item, const uint32_t* visb, int pad_e0, float gamma, float m,
+                              float* lse_p, float* lse_n, float* loss, void* stream);
+int gdm_circle_match_bwd2_hip(const void* xrows, const void* xtp, const float* xpad, const void* yrows, const void* ytp,
+                              int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,
+                              const uint32_t* nbr, int nbr_per_item, const uint32_t* visb, int pad_e0, float gamma, float m,
+                              const float* lse_p, const float* lse_n, const float* coef, float* gx, float* gy_part, void* stream);
 int gdm_circle_match_bwd_parts(int R, int M);
 int gdm_circle_match_bwd_hip(const void* xrows, const void* xtp, const float* xsum, const void* yrows, const void* ytp,
                              int R, int M, const int32_t* g, const int32_t* c2, const int32_t* item,

@@ -9,7 +9,9 @@ writes it (materialised [n_i, M+1] similarity, explicit boolean mask, masked log
   matching_loss_sys           /root/reference/models/geoMatch.py:86-100  (symmetric objects: two positive columns per row)
   pointwise_feature_matching  /root/reference/models/geoMatch.py:102-157
 
-Pinned by tests/golden/losses.npz and losses_sym.npz (values and gradients produced by the imported reference,
+  dgcnn_pointwise_feature_matching   /root/reference/models/geoMatch_DGCNN.py:52-135 (padding column e0, per-item per-vertex radius)
+
+Pinned by tests/golden/losses.npz, losses_sym.npz and dgcnn_losses.npz (values and gradients produced by the imported reference,
 tests/golden/make_golden.py); the product's fused HIP kernels are compared with these functions and with the goldens.
 """
 import torch
@@ -79,6 +81,43 @@ def pointwise_feature_matching(rgbd_feature, mesh_feature, labels, match_idx, vi
         else:
             mask = positive_mask(match_idx[i].index_select(0, idxs).long(), mesh_xyz, visible_flag[i], radius)
         losses.append(circle_loss(sim, mask))
+    if not losses:
+        return torch.zeros(())
+    return torch.mean(torch.stack(losses))
+
+
+def dgcnn_positive_mask(match_idx, mesh_xyz, vis_flag, RT, positive_r):
+    """geoMatch_DGCNN.py:52-74: as positive_mask, but the radius of column v is positive_r / 1000 * z of v posed by RT (:65-66)."""
+    n_node = len(mesh_xyz)
+    on = match_idx != n_node
+    vis = vis_flag.to(torch.bool)
+    vis_pts = mesh_xyz[vis]
+    proj = torch.matmul(vis_pts, RT[:, :3].t()) + RT[:, 3:].t()
+    radius = positive_r / 1000.0 * proj[:, 2]
+    near = pdist(mesh_xyz[match_idx[on]], vis_pts) < radius
+    mask = torch.zeros((len(match_idx), n_node), dtype=torch.bool)
+    rows = torch.zeros((int(on.sum()), n_node), dtype=torch.bool)
+    rows[:, vis] = near
+    mask[on] = rows
+    return torch.cat([mask, (~on).unsqueeze(1)], dim=1)
+
+
+def dgcnn_pointwise_feature_matching(rgbd_feature, mesh_feature, origin_labels, match_idx, visible_flag, RT, mesh_xyz, positive_r=3):
+    """geoMatch_DGCNN.py:80-135: every point normalised, one similarity for the batch against the mesh padded with e0, rows picked by
+    origin_labels, items with fewer than 3 rows skipped."""
+    B, D, _ = rgbd_feature.shape
+    rgbd = F.normalize(rgbd_feature.transpose(1, 2), p=2, dim=2)
+    padding = torch.zeros((D, 1), dtype=torch.float32)
+    padding[0] = 1
+    mesh_padded = F.normalize(torch.cat([mesh_feature[0], padding], dim=1), p=2, dim=0)
+    sim = torch.matmul(rgbd, mesh_padded)
+    losses = []
+    for i in range(B):
+        idxs = torch.where(origin_labels[i] == 1)[0]
+        if len(idxs) < 3:
+            continue
+        mask = dgcnn_positive_mask(match_idx[i].index_select(0, idxs).long(), mesh_xyz, visible_flag[i], RT[i], positive_r)
+        losses.append(circle_loss(sim[i][idxs, :], mask))
     if not losses:
         return torch.zeros(())
     return torch.mean(torch.stack(losses))

@@ -31,6 +31,30 @@ def loss_inputs(M=512, Bl=2, Nl=256, seed=11):
     return d
 
 
+def dgcnn_loss_inputs(M=384, Bl=3, Nl=256, seed=31):
+    """Training matching of the geoMatch_DGCNN variant (geoMatch_DGCNN.py:52-135): three items -- the last with fewer than three rows
+    of origin_labels == 1 (skipped by the reference) -- and a pose per item that puts the model 0.6 .. 1.0 m in front of the camera."""
+    rs = np.random.RandomState(seed)
+    labels = (rs.rand(Bl, Nl) < 0.6).astype(np.int64)
+    labels[Bl - 1] = 0
+    labels[Bl - 1, :2] = 1
+    RT = np.zeros((Bl, 3, 4), np.float32)
+    for b in range(Bl):
+        q, _ = np.linalg.qr(rs.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        RT[b, :, :3] = q
+        RT[b, :, 3] = (0.05 * rs.randn(), 0.05 * rs.randn(), 0.6 + 0.4 * rs.rand())
+    return dict(
+        rgbd_f=rs.randn(Bl, 128, Nl).astype(np.float32),
+        mesh_f=rs.randn(1, 128, M).astype(np.float32),
+        origin_labels=labels,
+        match_idx=rs.randint(0, M + 1, size=(Bl, Nl)).astype(np.int64),
+        vis=(rs.rand(Bl, M) < 0.5).astype(np.float32),
+        RT=RT,
+    )
+
+
 def sym_loss_inputs(M=512, Bl=2, seed=23):
     """Symmetric-object training matching (geoMatch.py:86-100): the reference indexes the per-vertex symmetry table with POINT
     indices and the per-point match table with its values, so the fixture keeps N == M (as the reference's default 4096/4096)."""

@@ -338,6 +338,66 @@ def test_symmetric_object_matching_loss_vs_reference_golden(golden_model):
         del model.model_emb._buffers["sys_idx"]
 
 
+def test_dgcnn_variant_matching_loss_on_fused_kernels_vs_reference_golden():
+    """The geoMatch_DGCNN variant's training matching loss (geoMatch_DGCNN.py:52-135) on the fused circle-match kernels -- padding
+    column e0, one positive table per item from the per-vertex radius positive_r / 1000 * z(RT v) -- without any [B, N, M + 1] tensor:
+    (1) value and both gradients vs the imported reference (tests/golden/dgcnn_losses.npz); (2) at the reference's training shape
+    (N = M = 4096, batch 3) vs oracle/loss_ref's restatement of the reference loop."""
+    from geometric_aware_dense_matching_amd.geoMatch_DGCNN import GeoMatch as GeoMatchDGCNN
+    from oracle import loss_ref
+    g = np.load(os.path.join(G, "dgcnn_losses.npz"))
+    li = gin.dgcnn_loss_inputs()
+    dev = torch.device("cuda")
+    Md = g["mesh_xyz"].shape[0]
+    dg = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=Md), 1,
+                       model_points=synthetic.make_model_points(1, Md)).to(dev).train()
+    assert not hasattr(dg, "matching_loss")                                        # the per-item transcription is gone
+    with torch.no_grad():
+        dg.model_emb.mesh.copy_(torch.from_numpy(g["mesh_buffer"]).to(dev))
+    dg.positive_r = float(g["positive_r"])
+    rgbd = torch.from_numpy(li["rgbd_f"]).to(dev).requires_grad_(True)
+    mesh = torch.from_numpy(li["mesh_f"]).to(dev).requires_grad_(True)
+    x = dict(origin_labels=torch.from_numpy(li["origin_labels"]).to(dev), match_idx=torch.from_numpy(li["match_idx"]).to(dev),
+             visible_flag=torch.from_numpy(li["vis"]).to(dev), RT=torch.from_numpy(li["RT"]).to(dev))
+    torch.cuda.reset_peak_memory_stats()
+    ml = dg.pointwise_feature_matching(rgbd, mesh, x)
+    ml.backward()
+    assert abs(ml.item() - float(g["match_loss"])) < 1e-4 * max(1.0, abs(float(g["match_loss"])))
+    assert np.allclose(rgbd.grad.cpu().numpy(), g["rgbd_grad"], rtol=2e-3, atol=1e-6)
+    assert np.allclose(mesh.grad.cpu().numpy(), g["mesh_grad"], rtol=2e-3, atol=1e-6)
+    # (2) training shape against the oracle loop
+    rs = np.random.RandomState(5)
+    B, N, M = 3, 4096, 4096
+    big = GeoMatchDGCNN(dict(feat_dim=128, k=16, embed_dim=1024, dropout=0.1, n_mesh_node=M), 1,
+                        model_points=synthetic.make_model_points(1, M)).to(dev).train()
+    big.positive_r = 12
+    mesh_xyz = big.model_emb.mesh[0][:3, :].transpose(0, 1).contiguous()
+    RT = np.zeros((B, 3, 4), np.float32)
+    for b in range(B):
+        q, _ = np.linalg.qr(rs.randn(3, 3))
+        RT[b, :, :3] = q if np.linalg.det(q) > 0 else -q
+        RT[b, :, 3] = (0.0, 0.0, 0.7 + 0.1 * b)
+    xs = dict(origin_labels=torch.from_numpy((rs.rand(B, N) < 0.5).astype(np.int64)), match_idx=torch.from_numpy(rs.randint(0, M + 1, (B, N))),
+              visible_flag=torch.from_numpy((rs.rand(B, M) < 0.6).astype(np.float32)), RT=torch.from_numpy(RT))
+    rg = torch.from_numpy(rs.randn(B, 128, N).astype(np.float32)).requires_grad_(True)
+    mf = torch.from_numpy(rs.randn(1, 128, M).astype(np.float32)).requires_grad_(True)
+    want = loss_ref.dgcnn_pointwise_feature_matching(rg, mf, xs["origin_labels"], xs["match_idx"], xs["visible_flag"], xs["RT"],
+                                                     mesh_xyz.cpu(), positive_r=12)
+    want.backward()
+    rgd = rg.detach().to(dev).requires_grad_(True)
+    mfd = mf.detach().to(dev).requires_grad_(True)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    got = big.pointwise_feature_matching(rgd, mfd, {k: v.to(dev) for k, v in xs.items()})
+    got.backward()
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < B * N * (M + 1) * 4 // 2       # no [B, N, M + 1] similarity (201 MB) was ever formed
+    assert abs(got.item() - want.item()) < 2e-5 * max(1.0, abs(want.item()))
+    assert torch.allclose(rgd.grad.cpu(), rg.grad, rtol=2e-3, atol=2e-7)
+    assert torch.allclose(mfd.grad.cpu(), mf.grad, rtol=2e-3, atol=2e-7)
+
+
 def test_fused_matching_loss_training_shape_and_empty_positive_sets():
     """Default training shape of the reference (N = M = 4096, config/lmo_cfg.py:95-98) on 2 items: fused == materialised form;
     rows whose ground-truth vertex is invisible (empty positive set) give loss 0 and gradient 0, no NaN."""

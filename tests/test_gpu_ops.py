@@ -47,6 +47,57 @@ def test_knn_duplicates_canonical_order(ops):
     assert np.array_equal(got_d2.cpu().numpy(), want_d2)
 
 
+@pytest.mark.parametrize("case", ["cube", "sheet", "clusters", "line_x", "line_y", "point", "dups", "outside", "k32", "big", "holes", "few"])
+def test_knn_cell_list_search_equals_oracle(ops, case):
+    """The cell-list search (knn_cells_bin_kernel + knn_cells_kernel: unorganised supports of >= 1024 points through ops.knn_jobs) is
+    exact on any data -- indices and (through the oracle's arithmetic) the (d2, index) order bit for bit: a uniform cube (the K-th
+    neighbour is often outside the first 3 x 3 cells), a thin depth sheet like a real crop, tight clusters (most cells empty), all points
+    on one line (a degenerate axis), one repeated point, exact duplicates (ties by index), queries far outside the support's bounding
+    box, K = 32, 16384 points, points at the origin among real ones (depth holes), and a support barely over the threshold with K
+    close to the cell population."""
+    from oracle import knn as oknn
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    B, S, Q, K = 2, 2048, 1500, 16
+    qry = None
+    if case == "cube":
+        sup = rs.rand(B, S, 3).astype(np.float32)
+    elif case == "sheet":
+        xy = rs.rand(B, S, 2).astype(np.float32) * 0.3 - 0.15
+        z = (0.8 + 0.05 * np.sin(7 * xy[..., :1]) * np.cos(5 * xy[..., 1:])).astype(np.float32)
+        sup = np.concatenate([xy, z], axis=2)
+    elif case == "clusters":
+        c = rs.rand(B, 8, 3).astype(np.float32)
+        sup = (c[:, rs.randint(0, 8, S)] + 0.002 * rs.randn(B, S, 3)).astype(np.float32)
+    elif case in ("line_x", "line_y"):
+        sup = rs.rand(B, S, 3).astype(np.float32)
+        sup[..., 0 if case == "line_x" else 1] = 0.25
+    elif case == "point":
+        sup = np.tile(np.float32([[0.1, -0.2, 0.7]]), (B, S, 1))
+    elif case == "dups":
+        base = rs.rand(B, 1100, 3).astype(np.float32)
+        sup = np.concatenate([base, base[:, :948]], axis=1)
+    elif case == "outside":
+        sup = rs.rand(B, S, 3).astype(np.float32)
+        qry = (rs.rand(B, Q, 3) * 6 - 3).astype(np.float32)
+    elif case == "k32":
+        sup, K = rs.rand(B, S, 3).astype(np.float32), 32
+    elif case == "big":
+        S, Q = 16384, 700
+        sup = rs.rand(B, S, 3).astype(np.float32)
+    elif case == "holes":
+        sup = rs.rand(B, S, 3).astype(np.float32) + np.float32([0, 0, 0.5])
+        sup[:, rs.rand(S) < 0.1] = 0.0
+    else:
+        S, Q, K = 1024, 300, 20
+        sup = rs.rand(B, S, 3).astype(np.float32)
+    if qry is None:
+        qry = sup[:, :Q].copy() if case in ("sheet", "dups", "holes") else rs.rand(B, Q, 3).astype(np.float32)
+    want = oknn.knn_batch(sup, qry, K)
+    (got,) = ops.knn_jobs([(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), K)], B)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+
+
 def test_knn_reference_parity_tie_free(ops):
     """Against the REAL reference (nanoflann, oracle/_ref) when its build travelled with the snapshot."""
     from oracle import knn as oknn

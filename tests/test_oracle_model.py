@@ -211,6 +211,24 @@ def test_training_matching_loss_matches_reference_golden():
     assert np.allclose(mesh.grad.numpy(), gs["mesh_grad"], rtol=1e-4, atol=1e-8)
 
 
+def test_dgcnn_training_matching_loss_matches_reference_golden():
+    """oracle/loss_ref.dgcnn_pointwise_feature_matching vs the imported reference's geoMatch_DGCNN.pointwise_feature_matching
+    (geoMatch_DGCNN.py:52-135; tests/golden/make_golden_dgcnn_loss.py): value and both gradients, incl. an item the reference skips."""
+    from oracle import loss_ref
+    g = np.load(os.path.join(G, "dgcnn_losses.npz"))
+    li = gin.dgcnn_loss_inputs()
+    rgbd = torch.from_numpy(li["rgbd_f"]).requires_grad_(True)
+    mesh = torch.from_numpy(li["mesh_f"]).requires_grad_(True)
+    ml = loss_ref.dgcnn_pointwise_feature_matching(rgbd, mesh, torch.from_numpy(li["origin_labels"]), torch.from_numpy(li["match_idx"]),
+                                                   torch.from_numpy(li["vis"]), torch.from_numpy(li["RT"]), torch.from_numpy(g["mesh_xyz"]),
+                                                   positive_r=float(g["positive_r"]))
+    ml.backward()
+    assert abs(ml.item() - float(g["match_loss"])) < 1e-6 * max(1.0, abs(float(g["match_loss"])))
+    assert np.allclose(rgbd.grad.numpy(), g["rgbd_grad"], rtol=1e-4, atol=1e-8)
+    assert np.allclose(mesh.grad.numpy(), g["mesh_grad"], rtol=1e-4, atol=1e-8)
+    assert np.abs(g["rgbd_grad"][2]).max() == 0.0                                  # the third item has two labelled rows: skipped
+
+
 def test_front_end_arithmetic_matches_reference_dpt_2_pcld():
     """synthetic.depth_to_xyz (the host generator every test input comes from) == the reference's dpt_2_pcld + float32 cast,
     and the oracle's strided grids == the loader's sr2dptxyz, by SHA-256 of the float32 bytes (tests/golden/frontend.npz)."""
