@@ -166,6 +166,7 @@ SIGNATURES["gdm_mfma_probe_lds_hip"] = (_i, [_i, _i, _i, _vp, _vp])
 SIGNATURES["gdm_copy_jobs_hip"] = (_i, [ctypes.POINTER(CopyJob), _i, _vp])
 SIGNATURES["gdm_pointwise_chain2_hip"] = (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["gdm_pointwise_jobs_hip"] = (_i, [ctypes.POINTER(PwJob), _i, _i, _i, _i, _vp])
+SIGNATURES["gdm_pointwise2_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 SIGNATURES["gdm_pointwise_hip"] = (_i, [ctypes.POINTER(PwSeg), _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp])
 
 _lib = None

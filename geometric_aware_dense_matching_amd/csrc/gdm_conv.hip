@@ -390,11 +390,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                                                                  unsigned char* __restrict__ outpk = nullptr, int stride = 1,
                                                                  // per-image weights (the weight-gradient GEMM: image b of a workgroup's 256 pixels --
                                                                  // H*W % 256 == 0 -- reads its rows at wpk + b * wbstride); 0 = shared weights
-                                                                 long wbstride = 0,
-                                                                 // 1: the grid is (channel tiles, pixel tiles) -- consecutive workgroups share
-                                                                 // a pixel tile (development switch: measured no faster and heavier on the
-                                                                 // fabric than pixel tiles fastest, see conv1x1_launch)
-                                                                 int co_fastest = 0)
+                                                                 long wbstride = 0)
 {
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
@@ -411,7 +407,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     const int npanel = TAPS * nchunk;
     const int hw = H * W;
     const long ptot = rowidx ? (long)B : (long)B * hw;              // host: ptot % MF_WPIX == 0 (and hw % MF_WPIX == 0 for maps)
-    const unsigned bx = co_fastest ? blockIdx.y : blockIdx.x, by = co_fastest ? blockIdx.x : blockIdx.y;
+    const unsigned bx = blockIdx.x, by = blockIdx.y;
     const long pix0 = (long)bx * (WV * MF_WPIX) + wave * MF_WPIX;           // this wave's first pixel
     const int co0 = tile_co0 ? __builtin_amdgcn_readfirstlane(tile_co0[bx]) : by * (NCB * 16);
     const long pc = min(pix0, ptot - MF_WPIX);
@@ -783,16 +779,9 @@ extern "C" int gdm_mfma_probe_hip(int blocks, int iters, int chain, float* sink,
 static bool cin_ok(int Cin) { return Cin == 64 || (Cin >= 128 && Cin % 128 == 0); }
 
 // 64-channel output tiles instead of 128-channel ones: when the 128-channel tiling gives fewer workgroups than the chip has CUs, or
-// the layer has only 64 output channels (GDM_CONV_NCB=8 / 4 forces one form: development)
+// the layer has only 64 output channels
 static bool narrow_tiles(unsigned pixel_tiles, int Cout)
 {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("GDM_CONV_NCB");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 8) return false;
-    if (forced == 4) return true;
     return Cout <= 64 || (long)pixel_tiles * ((Cout + 127) / 128) < 256;
 }
 
@@ -907,12 +896,7 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
             attr4 = true;
         }
         // still fewer workgroups than CUs (128 -> 128 at 32 x 32, batch 16: 64 x 2): 128-pixel workgroups of four waves
-        static int half_env = -1;
-        if (half_env < 0) {
-            const char* e = getenv("GDM_CONV_HALF_TILES");
-            half_env = (e && e[0] == '0') ? 0 : 1;
-        }
-        if (half_env && Cin != 64 && (long)grid4.x * grid4.y < 256 && ptot % (CV_PIX / 2) == 0) {
+        if (Cin != 64 && (long)grid4.x * grid4.y < 256 && ptot % (CV_PIX / 2) == 0) {
             const dim3 grid4h(gdm_cdiv(ptot, CV_PIX / 2), grid4.y);
             static bool attr4h = false;
 #define CV4H(A, R) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, 8, 4, MF_WAVES / 2>), grid4h, dim3(CONV_THREADS / 2), SMEM4, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
@@ -1035,11 +1019,9 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     const unsigned ptiles = gdm_cdiv(ptot, CV_PIX);
     const bool narrow = (GDM_CONV_SHAPE == 16) && Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
     const unsigned ctiles = gdm_cdiv(Cout, narrow ? 64 : CV_CO);    // the last block's rows beyond Cout are zero weights, never stored
-    // GDM_CONV_CO_FASTEST=1 (development): channel tile = the fast grid axis (the kernel's co_fastest).  Measured on the 1024 -> 2304
-    // tap GEMM: same time, MORE fabric traffic (PMC 903 MB vs 573 MB per launch: each XCD then streams every weight panel), so off
-    static const int co_env = getenv("GDM_CONV_CO_FASTEST") ? atoi(getenv("GDM_CONV_CO_FASTEST")) : 0;
-    const int co_fast = (GDM_CONV_SHAPE == 16) && co_env > 0 && ptiles <= 65535;
-    const dim3 grid = co_fast ? dim3(ctiles, ptiles) : dim3(ptiles, ctiles);
+    // pixel tiles are the fast grid axis: workgroups that share a pixel tile land on one XCD.  (Channel tiles fastest was measured on the
+    // 1024 -> 2304 tap GEMM in round 3: same time, 903 MB instead of 573 MB of fabric traffic -- each XCD then streams every weight panel.)
+    const dim3 grid(ptiles, ctiles);
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
@@ -1053,7 +1035,7 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     }
     if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
 #if GDM_CONV_SHAPE == 16
-#define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride, 0L, co_fast
+#define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride
 #else
 #define C1TAIL
 #endif

@@ -454,13 +454,11 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     // feeds two points: measured SLOWER (71 -> 82 us and 75 -> 120 us per block of two stages at batch 16): the deep levels have
     // 2048 / 512 points in all, and halving the workgroups costs more than the shared loads save
     // default: the MFMA form at every level, one point per thread group at D = 32 / 64 and two above (GDM_LFA_MFMA=0: the FMA form
-    // everywhere; = D0 > 1: the MFMA form from D0 up; GDM_LFA_MFMA_PP=1 / 2: points per thread group in the MFMA form -- development
-    // switches).  Per block of two stages at batch 16 (tools/bench_lfa.py, FMA -> MFMA): 109 -> 96, 82 -> 69, 70 -> 60, 73 -> 60 us;
+    // everywhere; = D0 > 1: the MFMA form from D0 up -- the A/B switch of tools/bench_lfa.py).  Per block of two stages at batch 16 (tools/bench_lfa.py, FMA -> MFMA): 109 -> 96, 82 -> 69, 70 -> 60, 73 -> 60 us;
     // whole step (eager / hipGraph replay, one box): FMA at D = 32 only 3.830 / 3.957 ms, MFMA everywhere 3.807 / 3.942 ms
     static const int mf_env = getenv("GDM_LFA_MFMA") ? atoi(getenv("GDM_LFA_MFMA")) : 1;
-    static const int mfpp_env = getenv("GDM_LFA_MFMA_PP") ? atoi(getenv("GDM_LFA_MFMA_PP")) : 0;
     if (mf_env && D >= (mf_env > 1 ? mf_env : 32)) {
-        const int pp = mfpp_env ? (mfpp_env == 1 ? 1 : 2) : (D <= 64 ? 1 : 2);
+        const int pp = D <= 64 ? 1 : 2;
         const int P = (256 / D) * pp;
         dim3 g(gdm_cdiv(n, P), B);
 #define GDM_LFA_MF(DD) do { if (pp == 1) hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 1>), g, dim3(256), 0, s, a); \
@@ -472,8 +470,7 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
 #undef GDM_LFA_MF
         return gdm_launch_status("lfa_stage_mfma_kernel");
     }
-    static const int pp_env = getenv("GDM_LFA_PP") ? atoi(getenv("GDM_LFA_PP")) : 0;
-    const int PP = pp_env == 2 ? 2 : 1;
+    const int PP = 1;
     const int P = (256 / D) * PP;
     dim3 grid(gdm_cdiv(n, P), B);
     if (D == 32) hipLaunchKernelGGL((lfa_stage_kernel<32, 1>), dim3(gdm_cdiv(n, 8), B), dim3(256), 0, s, a);

@@ -1070,7 +1070,6 @@ extern "C" int gdm_match_packed_hip(const void* scene_rows, const void* model_ro
         // one workgroup per CU (the panel takes the LDS): v2 queues two rounds; v3 runs one round of <= 256 workgroups,
         // which the store path prefers (tools/micro/store_pattern.hip: 5.9 vs 4.9 TB/s)
         int G = (pipe ? 256 : 512) / panels;
-        if (const char* ge = getenv("GDM_MATCH_G")) G = atoi(ge);
         if (G < 1) G = 1;
         if (G > nrb) G = nrb;
         if (G >= 8) G &= ~7;                                    // keep same-rows workgroups on one bid%8 class

@@ -35,7 +35,8 @@ struct PwSegDev {
 struct PwArgs {
     PwSegDev seg[MAXSEG];
     int nseg;
-    const float* wt;          // [K][Cout], K = sum of the segments' channels, rows in segment order
+    const float* wt;          // [K][Cout] (wks = Cout, wcs = 1), K = sum of the segments' channels, rows in segment order; or the layer's
+    long wks, wcs;            // weight as the module holds it, [Cout][K] (wks = 1, wcs = K: gdm_pointwise2_hip, the training path)
     const float* scale;       // [Cout] or NULL (1)
     const float* shift;       // [Cout] or NULL (0)
     float* out;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void pointwise_kernel(const PwArgs a)
         }
 #pragma unroll
         for (int r = 0; r < WV; ++r) {
-            const float* p = wtp + (long)min(k0 + w_row(r), K - 1) * Cout + wc;
+            const float* p = wtp + (long)min(k0 + w_row(r), K - 1) * a.wks + (long)wc * a.wcs;
             if (VEC) wr[r] = *reinterpret_cast<const float4*>(p);
             else wr[r].x = *p;
         }
@@ -331,8 +332,8 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                 if (sidx) col = min(max(sidx[pg[g]], 0), sn - 1);
                 xp[g] = sx + (pb[g] * sC + (k0 - seg_start + kq)) * (long)sn + col;
             }
-            const float* wp = a.wt + (long)(k0 + kq) * Cout + wcol;
-            const long xinc = 4L * sn, winc = 4L * Cout;
+            const float* wp = a.wt + (long)(k0 + kq) * a.wks + (long)wcol * a.wcs;
+            const long xinc = 4L * sn, winc = 4L * a.wks;
             const int nfull = (k1 - k0) / 4;                               // steps whose four rows all lie inside [k0, k1)
             // software pipeline in groups of four steps: group i + 1's 20 loads are issued BEFORE group i's 16 MFMAs (two register
             // sets, the loop unrolled by two so that both are statically indexed)
@@ -401,7 +402,7 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
             if (k0 + 4 * nfull < k1) {                                      // the last, partial step: rows past k1 contribute zero
                 const bool in = k0 + 4 * nfull + kq < k1;
                 const long back = in ? 0 : (long)(k0 + 4 * nfull + kq - (k1 - 1));      // out-of-range lanes re-read row k1 - 1
-                const float wraw = wp[-back * Cout];
+                const float wraw = wp[-back * a.wks];
                 const float wv = in ? wraw : 0.f;
                 float xraw[4];
                 if (VEC) {
@@ -568,6 +569,13 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
                                  int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major,
                                  void* stream)
 {
+    return gdm_pointwise2_hip(segs, nseg, wt, 0, scale, shift, B, n, Cout, act, slope, out, out_C, out_c0, point_major, stream);
+}
+
+extern "C" int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float* wt, int w_rowmajor, const float* scale, const float* shift,
+                                  int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major,
+                                  void* stream)
+{
     GDM_CHECK_ARG(segs && wt && out, "gdm_pointwise_hip: NULL pointer");
     GDM_CHECK_ARG(nseg >= 1 && nseg <= MAXSEG, "gdm_pointwise_hip: nseg=%d not in [1,%d]", nseg, MAXSEG);
     GDM_CHECK_ARG(B >= 1 && n >= 1 && Cout >= 1, "gdm_pointwise_hip: bad shape B=%d n=%d Cout=%d", B, n, Cout);
@@ -588,6 +596,8 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
     GDM_CHECK_ARG(((uintptr_t)out & 15) == 0, "gdm_pointwise_hip: out must be 16-byte aligned");
     a.nseg = nseg;
     a.wt = wt;
+    a.wks = w_rowmajor ? 1 : Cout;
+    a.wcs = w_rowmajor ? a.K : 1;
     a.scale = scale;
     a.shift = shift;
     a.out = out;
@@ -605,9 +615,8 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
     // K axis: 8 parts of two 16-channel groups (2x the workgroups) where K is deep, else 4 parts of four channel groups
     const long base = tiles * gdm_cdiv(Cout, 64);
     hipStream_t st = (hipStream_t)stream;
-    bool vec = (n % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    bool vec = (n % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)wt & 15) == 0) && !w_rowmajor;      // (the FMA form's 16-byte weight loads run along Cout)
     for (int s = 0; s < nseg; ++s) vec = vec && !segs[s].idx && (((uintptr_t)segs[s].x & 15) == 0);
-    if (getenv("GDM_PW_NOVEC")) vec = false;
 #define GDM_PW_LAUNCH(NW, KS, COUT_PER_WG)                                                                                          \
     do {                                                                                                                            \
         const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, COUT_PER_WG));                                                              \
@@ -620,7 +629,7 @@ extern "C" int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* 
         int ks = 1;
         while (ks < 8 && a.K / (2 * ks) >= 16 && tiles * gdm_cdiv(Cout, 16) * ks < 4096) ks *= 2;
         const dim3 grid((unsigned)tiles, gdm_cdiv(Cout, 16));
-        bool mvec = (n % 4 == 0) && !getenv("GDM_PW_NOVEC");
+        bool mvec = (n % 4 == 0);
         for (int sgi = 0; sgi < nseg; ++sgi) mvec = mvec && !segs[sgi].idx && (((uintptr_t)segs[sgi].x & 15) == 0) && segs[sgi].n_src % 4 == 0;
 #define GDM_PWM(KSV)                                                                                                    \
         do {                                                                                                             \
@@ -674,6 +683,8 @@ extern "C" int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, 
             a[m].seg[0] = PwSegDev{jb.x, nullptr, K, jb.n};
             a[m].nseg = 1;
             a[m].wt = jb.wt;
+            a[m].wks = Cout;
+            a[m].wcs = 1;
             a[m].scale = nullptr;
             a[m].shift = nullptr;
             a[m].out = jb.out;
@@ -687,7 +698,7 @@ extern "C" int gdm_pointwise_jobs_hip(const gdm_pw_job* jobs, int njobs, int B, 
             a[m].K = K;
             a[m].total = (long)B * jb.n;
             tiles += (a[m].total + PT - 1) / PT;
-            if (jb.n % 4 == 0 && ((uintptr_t)jb.x & 15) == 0 && !getenv("GDM_PW_NOVEC")) vecmask |= 1 << m;
+            if (jb.n % 4 == 0 && ((uintptr_t)jb.x & 15) == 0) vecmask |= 1 << m;
             ends[m] = (int)tiles;
             ++m;
         }

@@ -200,7 +200,7 @@ class FFB6DEmb(nn.Module):
         p2r_emb = self.nearest_interpolation(pre_layer(p_emb0), idx).view(bs, -1, hr, wr)
         return fuse_layer(torch.cat((rgb_emb0, p2r_emb), dim=1))
 
-    def forward(self, inputs, end_points=None, parts=False, side_first=None, stage_hook=None):
+    def forward(self, inputs, end_points=None, parts=False):
         """-> f32[B,128,N] (ffb6d.py:285: cat of the 64 image channels at the chosen pixels and the 64 point channels); parts=True
         returns the two halves un-concatenated, for a consumer that reads them in place (the fused per-point heads)."""
         if fused_eval(inputs["rgb"], self):
@@ -235,9 +235,7 @@ class FFB6DEmb(nn.Module):
         from . import pyramid as _pyr
         overlap = settings.USE_SIDE_STREAMS and "point" in settings.SIDE_PARTS and fused_eval(inputs["rgb"], self)
         if overlap and settings.USE_TWO_STREAM_PIPELINE:
-            return self._forward_two_streams(inputs, rgb_emb, parts, side_first, stage_hook)
-        if side_first is not None or stage_hook is not None:
-            raise RuntimeError("side_first / stage_hook are hooks of the two-stream pipeline")
+            return self._forward_two_streams(inputs, rgb_emb, parts)
         if not overlap:
             _pyr.wait_ready(inputs)
         p_emb, f_pc0 = self._stem_and_mlp1(inputs["cld_rgb_nrm"])             # [B,8,N,1] (+ the first block's mlp1 of it)
@@ -323,7 +321,7 @@ class FFB6DEmb(nn.Module):
                 return y0.unsqueeze(3), y1.unsqueeze(3)
         return self.rndla_pre_stages(x).unsqueeze(3), None
 
-    def _forward_two_streams(self, inputs, rgb_emb, parts, side_first=None, stage_hook=None):
+    def _forward_two_streams(self, inputs, rgb_emb, parts):
         """The inference forward as a two-stream pipeline (settings.USE_SIDE_STREAMS): the IMAGE stream (the current one) runs the
         trunk / up stages and the point-to-pixel fusions, the POINT stream (side stream 0) the RandLA blocks, the decoder layers and the
         pixel-to-point fusions.  Per stage each stream waits ONCE for the other's product (an event): the point stream for the image
@@ -350,16 +348,10 @@ class FFB6DEmb(nn.Module):
         S.wait_stream(M)
         to(S, inputs["cld_rgb_nrm"])
         with torch.cuda.stream(S):
-            if side_first is not None:
-                side_first()                                                  # independent work (the mesh branch) in front of the point
-                                                                              # stream's wait for the pyramid; joined with the stream at the end
             _pyr.wait_ready(inputs, cloud_only=True)                          # the point stream's own wait: the cloud's searches only
             p_emb, f_pc0 = self._stem_and_mlp1(inputs["cld_rgb_nrm"])         # [B,8,N,1] (+ the first block's mlp1 of it)
         ds_emb = []
         for i_ds in range(4):
-            if stage_hook is not None and stage_hook[0] == i_ds:
-                stage_hook[1]()                                               # independent work forked from here (the mesh branch): in a
-                                                                              # hipGraph its nodes then sit in front of this stage's
             rgb_emb0 = self.cnn_ds_stages[i_ds](rgb_emb)
             ev_rgb0 = event(M)
             bs, c, hr, wr = rgb_emb0.size()

@@ -177,9 +177,8 @@ class GeoMatch(nn.Module):
         return value
 
     def forward(self, inputs, end_points=None, defer_seg=False):
-        """defer_seg (inference with settings.USE_SIDE_STREAMS and the fused heads): the normalise / segmentation layers are left
-        running on side stream 0 and NOT joined -- `end_points["_seg_fork"]` holds the fork, which the caller joins after it has
-        launched what only needs the features (matching.match_tail does: the N x M arg-max then runs beside those five layers)."""
+        """defer_seg: accepted for callers of earlier rounds (a split of the fused heads onto a side stream was measured without gain and
+        removed in round 4); the forward is the same either way."""
         if not end_points:
             end_points = {}
         rgb = inputs["rgb"]
@@ -190,28 +189,7 @@ class GeoMatch(nn.Module):
         emb = (lambda x: self.pcd_emb(x, parts=True)) if (heads is not None and isinstance(self.pcd_emb, FFB6DEmb)) else self.pcd_emb
         if settings.USE_SIDE_STREAMS and "mesh" in settings.SIDE_PARTS and (not self.training) and rgb.is_cuda and not torch.is_grad_enabled():
             # the mesh branch depends on nothing in `inputs`: it runs on a side stream beside the RGB-D embedding
-            if settings.MESH_ON_POINT_STREAM and isinstance(self.pcd_emb, FFB6DEmb) and settings.USE_TWO_STREAM_PIPELINE and "point" in settings.SIDE_PARTS:
-                # the mesh branch at the head of the POINT stream, in front of its wait for the pyramid (development switch)
-                box = []
-                rgbd_emb = self.pcd_emb(inputs, parts=heads is not None, side_first=lambda: box.append(self.mesh_features()))
-                mesh_features = box[0]
-                mesh_features.record_stream(torch.cuda.current_stream(rgb.device))
-            elif (settings.MESH_FORK_AT >= 0 and isinstance(self.pcd_emb, FFB6DEmb) and settings.USE_TWO_STREAM_PIPELINE and "point" in settings.SIDE_PARTS
-                  and heads is not None):
-                # enqueued in front of encoder stage MESH_FORK_AT of the image stream (it only waits for an event recorded at the top, so
-                # in a hipGraph it is still a root): its nodes then sit beside that stage's convolutions instead of at the step's end
-                ev0 = torch.cuda.Event()
-                ev0.record(torch.cuda.current_stream(rgb.device))
-                box = []
-
-                def _mesh_fork():
-                    with ops.fork(rgb.device, 1, start=ev0) as f:
-                        mf = self.mesh_features()
-                        mr = ops.match_pack(mf, ops.MATCH_BF16X3) if settings.PACK_MESH_ROWS else None
-                    box.append((f, mf, mr))
-                rgbd_emb = self.pcd_emb(inputs, parts=True, stage_hook=(settings.MESH_FORK_AT, _mesh_fork))
-                late_join, mesh_features, mesh_rows = box[0]
-            elif settings.MESH_FORK_LATE:
+            if settings.MESH_FORK_LATE:
                 # enqueued BEHIND the embedding (it only waits for an event recorded before it): in a hipGraph the branch is still a
                 # root, but the executor -- which spreads a graph over very few hardware queues, in node order -- then keeps the image
                 # branch on a queue of its own instead of queueing layer1 behind the mesh kernels (tools/step_sequence.py, Queue_Id)
@@ -236,16 +214,7 @@ class GeoMatch(nn.Module):
         if heads is not None:
             # feature_encoding_layer, normalize_feature_layer, the residual add and seg_layer: nine per-point 1x1 convolutions, one launch
             a, b = rgbd_emb if isinstance(rgbd_emb, tuple) else (rgbd_emb, None)
-            if defer_seg and settings.USE_SIDE_STREAMS and settings.SPLIT_HEADS and len(heads[0]) == 8 and not self.training:
-                # two launches: the four feature layers here; normalise + residual + the segmentation layers on side stream 0, joined
-                # by the caller -- same layers, same operands (the fifth layer's operand rows are split from the same fp32 values)
-                rgbd_features, _ = ops.point_heads(a, b, heads[0][:4], None, feat_layer=3, res_layer=-1)
-                with ops.fork(rgb.device, 0) as sf:
-                    sf.use(rgbd_features, a, b)
-                    _, seg_features = ops.point_heads(rgbd_features, None, heads[0][4:], heads[1], feat_layer=-1, res_layer=0, residual=(a, b))
-                end_points["_seg_fork"] = sf
-            else:
-                rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
+            rgbd_features, seg_features = ops.point_heads(a, b, heads[0], heads[1], feat_layer=3, res_layer=4)
             if late_join is not None:
                 late_join.join(mesh_features, mesh_rows)
         else:

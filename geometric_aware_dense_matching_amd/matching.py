@@ -42,7 +42,6 @@ def match_tail(end_points, B, N, M, precision=ops.MATCH_BF16X3):
         srows, mrows = ops.match_pack2(rgbd, mesh[0] if mesh.dim() == 3 else mesh, precision)      # both packs, one launch
     else:
         srows = ops.match_pack(rgbd, precision)
-    pending = end_points.pop("_seg_fork", None)            # GeoMatch.forward(defer_seg=True): `seg` is still being formed on side stream 0
     if forked:
         with ops.fork(seg.device, 0) as f:                   # side stream 0: behind the segmentation layers, if they are pending there
             f.use(seg)
@@ -50,8 +49,6 @@ def match_tail(end_points, B, N, M, precision=ops.MATCH_BF16X3):
         bi, bs = ops.match_packed(srows, mrows, B, N, M, precision)
         f.join(mask, count, seg)
     else:
-        if pending is not None:
-            pending.join(seg)
         mask, count = ops.seg_mask(seg)
         bi, bs = ops.match_packed(srows, mrows, B, N, M, precision)
     return mask, count, bi, bs

@@ -36,17 +36,12 @@ _side_streams = {}
 
 
 def side_stream(device, which=0):
-    """A per-device side stream (HIP streams let independent branches of the step overlap: most of its ~230 kernels are far too
+    """A per-device side stream (HIP streams let independent branches of the step overlap: most of its ~120 kernels are far too
     small to fill 256 CUs).  Callers fork with side.wait_stream(current), join with current.wait_stream(side)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _side_streams.get(key)
     if st is None:
-        # GDM_SIDE_PRIORITY="k:p,..." (development): HIP stream priority p (-1 = high) for side stream k
-        prio = 0
-        for item in os.environ.get("GDM_SIDE_PRIORITY", "").split(","):
-            if ":" in item and int(item.split(":")[0]) == which:
-                prio = int(item.split(":")[1])
-        st = torch.cuda.Stream(device=device, priority=prio)
+        st = torch.cuda.Stream(device=device)
         _side_streams[key] = st
     return st
 
@@ -649,12 +644,13 @@ def _pw_seg(spec, B, name):
     return seg, (x, idx), n
 
 
-def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_major=False, out=None, out_c0=0):
+def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_major=False, out=None, out_c0=0, w_rowmajor=False):
     """One per-point (1x1) layer in one launch (include/gdm.h gdm_pointwise_hip), inference only:
         y[b,:,i] = act(scale * (W . cat(segs)[b,:,i]) + shift)
     segs: a list of one to three of  x f32[B,C,n(,1)]  or  (x f32[B,C,n_src(,1)], idx int[B,n(,1)])  -- the concat along channels
     is never formed, an indexed segment is read through its index (nearest-neighbour interpolation folded into the load).
-    wt f32[K,Cout]: the layer's weight TRANSPOSED (K = total input channels).
+    wt f32[K,Cout]: the layer's weight TRANSPOSED (K = total input channels); w_rowmajor: wt is f32[Cout,K] instead, the weight as an
+    nn.Conv1d / nn.Conv2d holds it (the training path: no transposed copy of a weight that changes every step).
     Returns f32[B,Cout,n], or f32[B,n,Cout] when point_major; with `out` (f32[B,outC,n] / [B,n,outC]) channels
     [out_c0, out_c0+Cout) of it are written instead."""
     if not isinstance(segs, list):
@@ -662,7 +658,7 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_m
     first = segs[0] if torch.is_tensor(segs[0]) else segs[0][0]
     B = first.shape[0]
     wt = _dev(wt, torch.float32, "wt")
-    K, Cout = wt.shape
+    K, Cout = (wt.shape[1], wt.shape[0]) if w_rowmajor else wt.shape
     arr = (_lib.PwSeg * len(segs))()
     keep = []
     n = None
@@ -685,9 +681,9 @@ def pointwise(segs, wt, scale=None, shift=None, act=ACT_NONE, slope=0.0, point_m
         outC = out.shape[2] if point_major else out.shape[1]
         if not out.is_contiguous() or out.dtype != torch.float32 or out.shape[0] != B or (out.shape[1] if point_major else out.shape[2]) != n:
             raise ValueError("pointwise: out must be a contiguous f32 [B,%s] tensor" % ("n,outC" if point_major else "outC,n"))
-    check(_lib.lib().gdm_pointwise_hip(arr, len(segs), wt.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                       shift.data_ptr() if shift is not None else None, B, n, Cout, int(act), float(slope),
-                                       out.data_ptr(), outC, int(out_c0), 1 if point_major else 0, _stream()), "gdm_pointwise_hip")
+    check(_lib.lib().gdm_pointwise2_hip(arr, len(segs), wt.data_ptr(), 1 if w_rowmajor else 0, scale.data_ptr() if scale is not None else None,
+                                        shift.data_ptr() if shift is not None else None, B, n, Cout, int(act), float(slope),
+                                        out.data_ptr(), outC, int(out_c0), 1 if point_major else 0, _stream()), "gdm_pointwise_hip")
     return out
 
 
@@ -1007,6 +1003,8 @@ class _WxTrain(torch.autograd.Function):
         Cout = w2.shape[0]
         if x3.is_cuda and _gemm_fwd_mfma_ok(Cin, Cout, n, B):
             return gemm_bf16x3(x3, gemm_pack_weight(w2), Cout)
+        if settings.USE_POINTWISE_TRAIN and x3.is_cuda:
+            return pointwise([x3], w2, w_rowmajor=True)
         return torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x3)
 
     @staticmethod
@@ -1019,6 +1017,8 @@ class _WxTrain(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if x3.is_cuda and _gemm_fwd_mfma_ok(Cout, Cin, n, B):
                 gx = gemm_bf16x3(go, gemm_pack_weight(w2.t().contiguous()), Cin)
+            elif settings.USE_POINTWISE_TRAIN and x3.is_cuda:
+                gx = pointwise([go], w2)
             else:
                 gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go)
         if ctx.needs_input_grad[1]:
@@ -1046,6 +1046,10 @@ class _Conv1x1Train(torch.autograd.Function):
         ctx.has_bias = bias is not None
         y = torch.empty((B, w2.shape[0]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)   # returned as it is (not a view: the
         y3 = y.view(B, w2.shape[0], -1)                                                            # modules' in-place activations follow)
+        if settings.USE_POINTWISE_TRAIN and x3.is_cuda and x3.is_contiguous():
+            # own exact-fp32 MFMA kernel, the module's [Cout, Cin] weight read in place, the bias in its epilogue
+            pointwise([x3], w2, None, bias, ACT_NONE, 0.0, out=y3, w_rowmajor=True)
+            return y
         torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x3, out=y3)
         if bias is not None:
             y3 += bias.view(1, -1, 1)
@@ -1058,7 +1062,10 @@ class _Conv1x1Train(torch.autograd.Function):
         go3 = go.reshape(B, w2.shape[0], -1)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go3).view(ctx.xshape)
+            if settings.USE_POINTWISE_TRAIN and go3.is_cuda:
+                gx = pointwise([go3.contiguous()], w2).view(ctx.xshape)     # W^T . go: the same weight read as [K = Cout][Cin]
+            else:
+                gx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), go3).view(ctx.xshape)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and wgrad_direct_supported(x3, go3, bias=want_gb):
             gw, gb = wgrad_direct(x3, go3, bias=want_gb)             # weight and bias gradient from one read of go

@@ -33,6 +33,7 @@ the initial values.
     USE_OWN_STEM               GDM_OWN_STEM               the stem (conv 7x7/2 + BN + ReLU + max-pool) as an MIOpen convolution + one fused BN/ReLU/pool launch
     USE_POINTWISE              GDM_POINTWISE              per-point 1x1 layers (point branch, fusion, decoder) as library GEMM + BN/activation kernel + torch.cat
     USE_MFMA_STRIDED           GDM_MFMA_STRIDED           stride-2 residual block (layer2.0) and the 1x1 downsample branches on MIOpen / hipBLASLt
+    USE_POINTWISE_TRAIN        GDM_POINTWISE_TRAIN        training: forward / input gradient of the small 1x1 layers as hipBLASLt fp32 batched GEMMs
     USE_POINT_CHAIN            GDM_POINT_CHAIN            the RandLA stem layer and the first block's mlp1 as two launches of the per-point kernel
     USE_PSP_JOBS               GDM_PSP_JOBS               the four prior products of the pyramid-pooling module as four launches of the per-point kernel
     STATIC_MATCH_ROWS          GDM_STATIC_MATCH_ROWS=1    (default off) matching loss over all B*N rows with zero weight on the unselected
@@ -68,22 +69,20 @@ USE_MFMA_GEMM_TRAIN = _flag("GDM_MFMA_GEMM_TRAIN")
 USE_GATHERED_FINAL = _flag("GDM_GATHERED_FINAL")
 USE_DIRECT_WGRAD = _flag("GDM_DIRECT_WGRAD")
 USE_FUSED_ADAM = _flag("GDM_FUSED_ADAM")
+USE_POINTWISE_TRAIN = _flag("GDM_POINTWISE_TRAIN")       # training: forward / input gradient of the small 1x1 layers on the own fp32-MFMA per-point kernel (off: hipBLASLt batched GEMMs)
 USE_POINT_CHAIN = _flag("GDM_POINT_CHAIN")               # the RandLA stem fc0 and the first block's mlp1 as one launch (gdm_pointwise_chain2_hip)
 USE_PSP_JOBS = _flag("GDM_PSP_JOBS")                     # the four prior products of the pyramid-pooling module in one launch (gdm_pointwise_jobs_hip)
 USE_PACKED_PRODUCERS = _flag("GDM_PACKED_PRODUCERS")     # psp_combine / the up-conv gather write the next GEMM's packed operand themselves
 USE_TWO_STREAM_PIPELINE = _flag("GDM_TWO_STREAM_PIPELINE")     # with USE_SIDE_STREAMS: image / point streams run ahead of each other, one event per stage and direction
 MESH_FORK_LATE = os.environ.get("GDM_MESH_FORK_LATE", "1") != "0"       # with USE_SIDE_STREAMS: the mesh fork is enqueued behind the embedding
-MESH_FORK_AT = int(os.environ.get("GDM_MESH_FORK_AT", "-1"))          # with USE_SIDE_STREAMS + the two-stream pipeline: the mesh fork is enqueued in front of encoder stage k (0..3) of the image stream; -1 = MESH_FORK_LATE decides
-MESH_ON_POINT_STREAM = os.environ.get("GDM_MESH_ON_POINT_STREAM", "0") == "1"   # development: the mesh branch at the head of the point stream
 PACK_MESH_ROWS = os.environ.get("GDM_PACK_MESH_ROWS", "1") != "0"         # with USE_SIDE_STREAMS: the model descriptors' matching rows are packed inside the mesh fork
-SPLIT_HEADS = os.environ.get("GDM_SPLIT_HEADS", "0") == "1"               # development: with USE_SIDE_STREAMS and forward(defer_seg=True) the heads run as two launches (measured: no gain, the arg-max kernel fills the chip)
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",
-                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN", "USE_MFMA_WGRAD", "USE_MFMA_GEMM_TRAIN", "USE_GATHERED_FINAL", "USE_DIRECT_WGRAD", "USE_PSP_JOBS", "USE_POINT_CHAIN")
+                "USE_FUSED_MATCH_LOSS", "USE_SIDE_STREAMS", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED", "USE_POINTWISE", "USE_OWN_STEM", "USE_GEMM_CONV1X1_TRAIN", "USE_MFMA_WGRAD", "USE_MFMA_GEMM_TRAIN", "USE_GATHERED_FINAL", "USE_DIRECT_WGRAD", "USE_PSP_JOBS", "USE_POINT_CHAIN", "USE_POINTWISE_TRAIN")
 # the switches behind which split-bf16 (x3, fp32 accumulate) products run in the eval forward: all off = fp32 products everywhere
 # (hipBLASLt / MIOpen / fp32 FMA kernels); the matching kernel's precision is its own argument (matching.match_frames(precision=))
 SPLIT_BF16_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_SPARSE_FINAL", "USE_FUSED_HEADS", "USE_MFMA_STRIDED",

@@ -110,9 +110,10 @@ class SyntheticCrops(torch.utils.data.Dataset):
     """Generated items with the loader's keys (datasets/lm/linemod_pbr.py:572-599): model inputs + labels,
     match_idx (index of the corresponding model vertex, M = 'no correspondence'), visible_flag, RT."""
 
-    def __init__(self, n_items, n_points, n_mesh, seed=0, cls_ids=None):
+    def __init__(self, n_items, n_points, n_mesh, seed=0, cls_ids=None, with_ids=True):
         self.n_items, self.n_points, self.n_mesh, self.seed = n_items, n_points, n_mesh, seed
         self.cls_ids = list(cls_ids) if cls_ids else None          # test split: item i is an instance of cls_ids[i % len]
+        self.with_ids = with_ids                                    # scene_id / im_id as a BOP test split carries them (evaluator.py:366-367)
 
     def __len__(self):
         return self.n_items
@@ -127,6 +128,8 @@ class SyntheticCrops(torch.utils.data.Dataset):
                   RT=np.eye(4, dtype=np.float32)[:3])
         if self.cls_ids:
             it["cls_id"] = np.int32(self.cls_ids[i % len(self.cls_ids)])
+        if self.with_ids:
+            it["scene_id"], it["im_id"] = np.int32(1 + self.seed), np.int32(i)
         return it
 
 
@@ -353,6 +356,7 @@ def test(args):
     prec_table = evaluation.RecallTable(precision=True)      # evaluator.py:466-660, written beside the recall table with --eval_output
     bop = evaluation.BopCsv()                                # evaluator.py:341,365-373: one line per predicted instance
     n_seen = 0
+    bop_ids_seen = True                                      # every batch so far carried scene_id / im_id
     sym_names = set(ds.get("sym_objs", ()))                 # config/*_cfg.py SYM_OBJS: object NAMES
     with torch.no_grad():
         for batch in loader:
@@ -379,12 +383,24 @@ def test(args):
                                                  sym_rots=getattr(model_dict[cid].model_emb, "sym_rots", None))
                     table.update(obj_name_of(ds, cid), err, ds["diameters"][cid] / 1000.0)
                     prec_table.update(obj_name_of(ds, cid), err, ds["diameters"][cid] / 1000.0)
-            # the reference keys a prediction by "scene/.../im_id" (evaluator.py:366-367); a loader without these fields gets the running
-            # instance number as im_id of scene 0
-            for i, cid in enumerate(cls):
-                scene = int(batch["scene_id"][i]) if "scene_id" in batch else 0
-                im = int(batch["im_id"][i]) if "im_id" in batch else n_seen + i
-                bop.add("%06d/%06d" % (scene, im), cid, out["RT"][i, :, :3], out["RT"][i, :, 3])
+            # The reference walks the GROUND-TRUTH annotations (evaluator.py:340-373): a csv line is appended only for a prediction that
+            # has a ground-truth entry, keyed by the real "scene/.../im_id" (:366-367), and a ground truth without a prediction counts as a
+            # miss in the recall table (:355-363).  So: lines only where the loader supplied RT AND scene_id / im_id (ids invented here
+            # would mean nothing to bop_toolkit and change with the batch order -- without them the csv is not written, see below), and
+            # `n_undetected` [bs] (ground truths of the instance's object in its image that the detector missed), when the loader
+            # carries it, goes to RecallTable.missing.
+            has_gt = "RT" in cu and cu["RT"].dim() == 3
+            has_ids = "scene_id" in batch and "im_id" in batch
+            bop_ids_seen = bop_ids_seen and has_ids
+            if has_gt and has_ids:
+                for i, cid in enumerate(cls):
+                    bop.add("%06d/%06d" % (int(batch["scene_id"][i]), int(batch["im_id"][i])), cid, out["RT"][i, :, :3], out["RT"][i, :, 3])
+            if has_gt and "n_undetected" in batch:
+                for i, cid in enumerate(cls):
+                    miss = int(batch["n_undetected"][i])
+                    if miss > 0:
+                        table.missing(obj_name_of(ds, cid), miss)
+                        prec_table.missing(obj_name_of(ds, cid), miss)      # (the precision variant ignores them: evaluator.py:549-551)
             n_seen += len(cls)
     if table.recalls:
         test.last_table = table
@@ -393,7 +409,13 @@ def test(args):
     if getattr(args, "eval_output", None) and args.local_rank == 0:
         # what the reference's evaluator leaves behind: the BOP result csv (:429-431) and, when ground truth was there, the error /
         # recall pickles and the table text of both variants (:449-455, :647-660)
-        written = [bop.write(os.path.join(args.eval_output, "%s_%s-test.csv" % (args.model_variant, args.dataset_name)))]
+        written = []
+        if bop_ids_seen and len(bop.lines) > 1:
+            written.append(bop.write(os.path.join(args.eval_output, "%s_%s-test.csv" % (args.model_variant, args.dataset_name))))
+        else:
+            import warnings
+            warnings.warn("train_lm test: the BOP result csv was NOT written: the dataset does not carry `scene_id` / `im_id` (or no "
+                          "instance had a ground-truth pose); the reference keys every csv line by them (evaluator.py:366-373)")
         if table.recalls:
             written += list(table.dump(args.eval_output, args.dataset_name + "_test"))
             written += list(prec_table.dump(args.eval_output, args.dataset_name + "_test", method_name=args.model_variant))

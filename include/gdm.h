@@ -524,6 +524,11 @@ typedef struct {
 } gdm_pw_seg;
 int gdm_pointwise_hip(const gdm_pw_seg* segs, int nseg, const float* wt, const float* scale, const float* shift,
                       int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
+/* The same layer with the weight as the module holds it when w_rowmajor != 0: wt f32[Cout,K] (nn.Conv1d / nn.Conv2d 1x1 weight), so
+ * the TRAINING forward W . x and input gradient W^T . go (wt = the same tensor read as [K' = Cout][Cout' = K], w_rowmajor = 0) of
+ * /root/reference/models/pytorch_utils.py:70-124 need no transposed copy of a weight that changes every step. */
+int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float* wt, int w_rowmajor, const float* scale, const float* shift,
+                       int B, int n, int Cout, int act, float slope, float* out, int out_C, int out_c0, int point_major, void* stream);
 /* Up to four independent plain layers out_j f32[B,Cout,n_j] = W_j^T . x_j (x_j f32[B,K,n_j], wt_j f32[K,Cout]; no scale / shift /
  * activation) of equal K >= 32 and Cout in ONE launch: the four prior products of the pyramid-pooling module
  * (/root/reference/models/cnn/pspnet.py:17-31, `stage(feats)` of the 1 / 2 / 3 / 6-bin pools folded with the bottleneck's slices).

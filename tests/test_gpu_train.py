@@ -106,7 +106,7 @@ def test_test_entry_point_runs(tmp_path):
     lines = open(out[0]).read().split("\n")
     assert os.path.basename(out[0]) == "ffb6d_lmo-test.csv" and lines[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(lines) == 1 + 4
     f = lines[2].split(",")
-    assert f[:4] == ["0", "000001", "1", "-1"] and f[6] == "-1"
+    assert f[1] == "000001" and f[2:4] == ["1", "-1"] and f[6] == "-1" and int(f[0]) >= 1      # the split's own scene / image ids
     assert np.allclose(np.array(f[4].split(" "), dtype=np.float64).reshape(3, 3), res[0]["RT"][1, :, :3].double().numpy(), atol=0)
     assert np.allclose(np.array(f[5].split(" "), dtype=np.float64), 1000 * res[0]["RT"][1, :, 3].double().numpy(), atol=0)
     if len(out) > 1:                                       # the synthetic loader carries ground-truth poses: both tables were dumped
@@ -114,6 +114,18 @@ def test_test_entry_point_runs(tmp_path):
         assert names == ["_lmo_test_errors.pkl", "_lmo_test_recalls.pkl", "_lmo_test_tab.txt", "ffb6d_lmo_test_errors.pkl",
                          "ffb6d_lmo_test_precisions.pkl", "ffb6d_lmo_test_tab_precisions.txt"]
         assert len(open(out[3]).read().splitlines()) == 19 and len(open(out[6]).read().splitlines()) == 18
+    # a split WITHOUT scene_id / im_id: the csv is refused (loudly) instead of being filled with invented ids; the tables are still dumped
+    import warnings
+    saved = train_lm.SyntheticCrops.__init__.__defaults__
+    train_lm.SyntheticCrops.__init__.__defaults__ = saved[:-1] + (False,)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            train_lm.test(args)
+        assert any("BOP result csv was NOT written" in str(x.message) for x in w)
+        assert not any(p.endswith(".csv") for p in train_lm.test.last_outputs)
+    finally:
+        train_lm.SyntheticCrops.__init__.__defaults__ = saved
 
 
 @pytest.mark.parametrize("entry,cls_id,extra", [("train_lm", 5, ""), ("train_ycb", 21, ""), ("train_ycb", 16, "--model-variant dgcnn")])
