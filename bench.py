@@ -77,7 +77,18 @@ def launch_ranks(args, argv, run=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this host driver
     env["GDM_BENCH_SPAWNED"] = "1"
-    return (run or subprocess.run)(cmd, env=env).returncode
+    if run is not None:
+        return run(cmd, env=env).returncode
+    # the ranks' stdout is relayed line by line: JSON lines (rank 0's result) to this process's stdout, anything else a library wrote
+    # there (gloo prints its connection notes to stdout) to stderr, so that stdout stays the ONE line the contract asks for
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in p.stdout:
+        if ln.lstrip().startswith("{"):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    return p.wait()
 
 
 def usable_cores():
@@ -258,10 +269,10 @@ def kernel_rooflines(torch, dev, B, N):
         pairs += 2 * hw * lv[3 - i]
     pairs *= B
     valu_peak = 256 * 4 * 32 * 2.4e9 / 9.0 / 1e12        # 9 vector ops per pair (3 sub, 3 mul, 2 add, 1 compare)
-    out.append({"kernel": "knn_wave_kernel + knn_grid_kernel + knn_kernel<1> (+ pack / range kernels): whole neighbour pyramid, 22 searches per crop", "bound": "valu",
+    out.append({"kernel": "knn_cells_kernel + knn_wave_kernel + knn_grid_kernel + knn_kernel<1> (+ bin / pack / range kernels): whole neighbour pyramid, 22 searches per crop", "bound": "valu",
                 "unit": "Tpair/s", "achieved": round(pairs / ms / 1e9, 3), "peak": round(valu_peak, 2),
                 "frac": round(pairs / ms / 1e9 / valu_peak, 4), "avg_ms": round(ms, 4),
-                "traffic": traffic("knn_wave_kernel", "knn_kernel<1>", "knn_grid_kernel"),
+                "traffic": traffic("knn_cells_kernel", "knn_wave_kernel", "knn_kernel<1>", "knn_grid_kernel"),
                 "work": "%d brute-force-equivalent pair distances per batch of %d crops (the searches against pixel grids visit a window, not all pairs); peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 9 vector ops per pair" % (pairs, B)})
     # (3) gather + max over K (random_sample, ffb6d.py:128-146): the largest call of the step, pixel -> point at 128 x 128
     C, n_src, m, K = 64, 128 * 128, N // 4, 16
@@ -290,7 +301,7 @@ def kernel_rooflines(torch, dev, B, N):
     out.append({"kernel": "conv_mfma16_kernel 1x1 1024->2304 @32x32 (tap GEMM of up_1)", "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(3 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(3 * fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_tflops": round(fl / ms / 1e9, 1), "avg_ms": round(ms, 4),
-                "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 8"),
+                "traffic": traffic("conv_mfma16_kernel<0, false, 1, false, 8, 9"),
                 "mfma_probe_tflops": None if not probe else round(probe, 1), "frac_of_probe": vs_probe(3 * fl / ms / 1e9),
                 "work": "2*Cin*Cout flops per pixel x3 split-bf16 products, B*H*W = %d pixels" % (B * 32 * 32)})
     # (5) the last image stage at the sampled pixels (up_3 + final at `choose`): replaces a 64 -> 64 3x3 convolution and a 1x1 + log-softmax

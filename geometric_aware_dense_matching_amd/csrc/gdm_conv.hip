@@ -395,10 +395,12 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     // H, W: OUTPUT map; the packed input is the (H stride) x (W stride) map (stride 2: layer2's first block, extractors.py:151-177)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
     constexpr int NS = NKS / 2;                                     // k-steps of 32 channels per chunk
-    constexpr int NPR = NCB / 2;                                    // pairs of output blocks
+    constexpr int UG = (NCB % 2 == 0) ? 2 : 3;                      // 16-channel output blocks per unit (NCB = 9: three)
+    constexpr int NPR = NCB / UG;                                   // units per k-step
     constexpr int PANEL = NCB * 16 * ROWB;                          // bytes of a weight panel in LDS
     constexpr int TST = NCB * 16 + 4;                               // floats per pixel row of a wave's output tile in LDS
-    static_assert(NCB == 8 || (NCB == 4 && !PIXMAJOR), "64-channel tiles: NCHW / packed output only");
+    static_assert(NCB == 8 || (NCB == 4 && !PIXMAJOR) || (NCB == 9 && !PIXMAJOR && WV == 8),
+                  "64-channel tiles: NCHW / packed output only; 144-channel tiles: NCHW fp32 output only (no packed output: a tile straddles 128-channel chunks)");
     constexpr int NPH = MF_NPH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform FOR THE COMPILER too: everything derived from it stays scalar
@@ -524,15 +526,15 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
         __syncthreads();                                            // panel `it` is in LDS; panel it-1's readers are done
         const bool more = it + 1 < npanel;
         const unsigned char* base = smem + (it & 1) * PANEL;
-        // units of (k-step S, pair of 16-channel output blocks): 6 NPH MFMAs of 16 cycles on 4 B fragments; PF units' reads in flight
+        // units of (k-step S, UG 16-channel output blocks): 3 UG NPH MFMAs of 16 cycles on 2 UG B fragments; PF units' reads in flight
         constexpr int PF = GDM_CONV16_PF;
         constexpr int NU = NPR * NS;
-        u32x4 fh[PF + 1][2], fl[PF + 1][2];
+        u32x4 fh[PF + 1][UG], fl[PF + 1][UG];
         auto frag_load = [&](int un) {
             const int S = un / NPR, pr = un % NPR, slot = un % (PF + 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = (2 * pr + j) * 16 + l16;
+            for (int j = 0; j < UG; ++j) {
+                const int col = (UG * pr + j) * 16 + l16;
                 fh[slot][j] = *reinterpret_cast<const u32x4*>(base + swz(col, 4 * S + kg));
                 fl[slot][j] = *reinterpret_cast<const u32x4*>(base + swz(col, 16 + 4 * S + kg));
             }
@@ -549,12 +551,12 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[S][ph]);
                 const bf16x8 al = __builtin_bit_cast(bf16x8, alo[S][ph]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 c = acc[ph][2 * pr + j];
+                for (int j = 0; j < UG; ++j) {
+                    f32x4 c = acc[ph][UG * pr + j];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, fl[slot][j]), c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, fh[slot][j]), c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, fh[slot][j]), c, 0, 0, 0);
-                    acc[ph][2 * pr + j] = c;
+                    acc[ph][UG * pr + j] = c;
                 }
             }
 #else
@@ -565,10 +567,10 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
 #pragma unroll
                 for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < UG; ++j) {
                         const bf16x8 av = __builtin_bit_cast(bf16x8, prod == 1 ? alo[S][ph] : ahi[S][ph]);
                         const bf16x8 bv = __builtin_bit_cast(bf16x8, prod == 0 ? fl[slot][j] : fh[slot][j]);
-                        acc[ph][2 * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[ph][2 * pr + j], 0, 0, 0);
+                        acc[ph][UG * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[ph][UG * pr + j], 0, 0, 0);
                     }
 #endif
             if (pr == NPR - 1 && S < NS - LATE) load_a(rnext, S);         // this k-step's registers are dead: next panel's data
@@ -582,9 +584,9 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
                 for (int S2 = NS - LATE; S2 < NS; ++S2) load_a(rcur, S2);
             }
 #pragma unroll
-            for (int i = 0; i < 6 * NPH; ++i) {
+            for (int i = 0; i < 3 * UG * NPH; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u + PF < NU && (i % NPH) == 0 && i < 4 * NPH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (u + PF < NU && (i % NPH) == 0 && i < 2 * UG * NPH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1017,6 +1019,29 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
     const unsigned ptiles = gdm_cdiv(ptot, CV_PIX);
+#if GDM_CONV_SHAPE == 16
+    // 144-channel tiles (nine 16-channel blocks) where they divide Cout and fill the chip's rounds better than 128-channel ones: the
+    // tap GEMMs of PSPUpsample have 9 * Cout' outputs -- 2304 at 64 pixel tiles = 1152 tiles of 128 (4.5 rounds of 256 CUs, paid as
+    // 5) or 1024 tiles of 144 (4 rounds); 576 at 256 pixel tiles = 1280 tiles of 128, the last of every five half empty, or 1024 of 144
+    if (Cin != 64 && !pixel_major && stride == 1 && Cout % 144 == 0 && GDM_CONV_GLDS) {
+        const long r128 = gdm_cdiv((long)ptiles * gdm_cdiv(Cout, 128), 256) * 128, r144 = gdm_cdiv((long)ptiles * (Cout / 144), 256) * 144;
+        if (r144 < r128) {
+            constexpr int PANEL9 = 9 * 16 * ROWB, TILE9 = CV_PIX * (9 * 16 + 4) * 4;
+            constexpr int SMEM9 = 2 * PANEL9 > TILE9 ? 2 * PANEL9 : TILE9;
+            static bool attr9 = false;
+            if (!attr9) {
+                (void)hipFuncSetAttribute((const void*)CONV_KERNEL<0, false, 1, false, 8, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM9);
+                (void)hipFuncSetAttribute((const void*)CONV_KERNEL<1, false, 1, false, 8, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM9);
+                attr9 = true;
+            }
+            const dim3 grid9(ptiles, Cout / 144);
+#define C19(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 8, 9>), grid9, dim3(CONV_THREADS), SMEM9, (hipStream_t)stream, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride)
+            if (act == 0) C19(0); else C19(1);
+#undef C19
+            return gdm_launch_status("conv1x1_bf16x3_kernel (144-channel tiles)");
+        }
+    }
+#endif
     const bool narrow = (GDM_CONV_SHAPE == 16) && Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
     const unsigned ctiles = gdm_cdiv(Cout, narrow ? 64 : CV_CO);    // the last block's rows beyond Cout are zero weights, never stored
     // pixel tiles are the fast grid axis: workgroups that share a pixel tile land on one XCD.  (Channel tiles fastest was measured on the

@@ -822,8 +822,32 @@ def batch_norm_act_train(x, bn, act=ACT_NONE, slope=0.0):
     module does) with a fused backward.  act: ACT_NONE / ACT_RELU / ACT_LEAKY(slope).  Caller checks bn_train_supported."""
     y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, slope, _sync_group(bn))
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _bn_counters is not None:
+            _bn_counters.append(bn.num_batches_tracked)           # one multi-tensor add for the whole forward (batched_bn_counters)
+        else:
+            bn.num_batches_tracked.add_(1)
     return y
+
+
+_bn_counters = None
+
+
+class batched_bn_counters:
+    """with ops.batched_bn_counters(): ... -- the `num_batches_tracked += 1` of every fused training BatchNorm inside the scope is applied
+    at its exit as ONE multi-tensor add instead of one tiny launch per layer (91 launches, 0.34 ms of a training step).  Same values
+    after the scope as the modules leave; nothing reads the counters inside a forward (momentum is a number in every layer here)."""
+
+    def __enter__(self):
+        global _bn_counters
+        self.prev, _bn_counters = _bn_counters, []
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_counters
+        pending, _bn_counters = _bn_counters, self.prev
+        if pending:
+            torch._foreach_add_(pending, 1)
+        return False
 
 
 def upconv3x3_gather(z, scale, shift, cout, out_size, act=ACT_NONE, slope=0.0, packed=False):

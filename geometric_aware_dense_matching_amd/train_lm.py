@@ -30,7 +30,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import infer, matching, pose, pyramid, settings, synthetic
+from . import infer, matching, ops, pose, pyramid, settings, synthetic
 from .checkpoint import load_checkpoint, save_checkpoint
 from .config import LMO_OBJS as LM_OBJS, dataset_config, make_dgcnn_cfg, make_model_cfg
 from .geoMatch import GeoMatch
@@ -156,7 +156,8 @@ def model_fn_dec(model, data, device):
     needs_pyramid = getattr(getattr(model, "module", model), "needs_pyramid", True)       # the DGCNN variant builds its own graphs
     if needs_pyramid and "cld_nei_idx0" not in cu:            # pyramid on the GPU (two launches per batch)
         cu.update(pyramid.build_pyramid(pyramid.cloud_from_inputs(cu["cld_rgb_nrm"]), cu["dpt_xyz"]))
-    return model(cu), cu
+    with ops.batched_bn_counters():                       # the 91 BatchNorm step counters as one multi-tensor add
+        return model(cu), cu
 
 
 class Trainer:

@@ -528,7 +528,8 @@ def test_final_stage_and_psp_pools(ops):
         assert torch.allclose(o.cpu(), torch.nn.functional.adaptive_avg_pool2d(f2, s_), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,n", [(2, 128, 256, 1024), (1, 1024, 2304, 1024), (1, 128, 16000, 8192), (2, 256, 576, 4096), (1, 128, 200, 64), (2, 64, 576, 4096), (1, 64, 128, 96)])
+@pytest.mark.parametrize("B,Cin,Cout,n", [(2, 128, 256, 1024), (1, 1024, 2304, 1024), (1, 128, 16000, 8192), (2, 256, 576, 4096), (1, 128, 200, 64), (2, 64, 576, 4096), (1, 64, 128, 96),
+                                          (16, 1024, 2304, 1024), (16, 256, 576, 4096)])      # the step's two tap GEMMs: 144-channel tiles
 def test_gemm_bf16x3(ops, B, Cin, Cout, n):
     rs = np.random.RandomState(Cin + n)
     x = torch.from_numpy(rs.randn(B, Cin, n).astype(np.float32))

@@ -1,7 +1,7 @@
 """Launches the step's dominant kernels a few times each at the shapes the step uses, for `rocprofv3 --pmc` passes:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_fetch -- python3 tools/pmc_kernels.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_write -- python3 tools/pmc_kernels.py
-    python tools/pmc_kernels.py --summarize out_fetch/*/*counter_collection.csv out_write/*/*counter_collection.csv > profiles/r03_pmc_traffic.json
+    python tools/pmc_kernels.py --summarize out_fetch/*/*counter_collection.csv out_write/*/*counter_collection.csv > profiles/r04_pmc_traffic.json
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md,
 HBM section), so it is doubled; other access widths are uncalibrated (noted per kernel in the output)."""
 import collections
@@ -19,9 +19,10 @@ KERNELS = collections.OrderedDict([
     ("match_pipe_kernel", ("N x 8192 descriptor kernel, fused arg-max", 4.0 * 128 * (B * N + M) + 8.0 * B * N)),
     ("conv_mfma16_kernel<0, false, 9, false, 8, 8", ("3x3 512->512 @32x32 (packed operands in, fp32 NCHW out)",
                                                        B * 34 * 34 * 4 * 512.0 + 9 * 4 * 512 * 512.0 + 4.0 * B * 512 * 1024)),
-    ("conv_mfma16_kernel<0, false, 1, false, 8, 8", ("1x1 1024->2304 @32x32 (tap GEMM of up_1)",
+    ("conv_mfma16_kernel<0, false, 1, false, 8, 9", ("1x1 1024->2304 @32x32 (tap GEMM of up_1, 144-channel tiles)",
                                                        B * 34 * 34 * 8 * 512.0 + 8 * 2304 * 512.0 + 4.0 * B * 2304 * 1024)),
-    ("knn_wave_kernel", ("K = 16 searches of the pyramid (unorganised supports)", None)),
+    ("knn_cells_kernel", ("the cloud's own K = 16 search (2048 x 2048 per crop), cell lists", None)),
+    ("knn_wave_kernel", ("K = 16 searches of the pyramid (small unorganised supports)", None)),
     ("knn_kernel<1>", ("K = 1 searches of the pyramid", None)),
     ("knn_grid_kernel", ("K = 16 searches against organised supports (window search)", None)),
     ("gather_max_", ("gather + max over K, C=64, 16384 px -> 512 points", 4.0 * B * (64 * 16384 + 16 * 512 + 64 * 512))),
