@@ -654,7 +654,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             try:
                 gp = infer.GraphedPipeline(model, inputs, precision=prec_name, with_pose=False, keep_pyramid=True,
-                                           forked=False if args.no_forked else "auto",
+                                           forked=False if args.no_forked else "auto", keep_both=True,
                                            capture_error_mode="thread_local" if world > 1 else None)
                 product_check = dict(gp.check, form=gp.form)
                 for form in gp.graphs:

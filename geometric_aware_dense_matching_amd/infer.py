@@ -88,10 +88,11 @@ class GraphedPipeline:
 
     All HIP operators of this package enqueue on torch's current stream with no host synchronisation and no allocation outside
     torch's graph-private pool, so they capture as they are; per-module caches (folded BN, packed weights, PReLU slopes) are filled
-    by the eager warm-up passes before the capture.  Each form owns its scratch buffers (ops.BufferPool)."""
+    by the eager warm-up passes before the capture.  Each form owns its scratch buffers (ops.BufferPool); the form that is not kept is
+    freed after the decision (keep_both=True keeps both: `replay(form)`)."""
 
     def __init__(self, model, example_inputs, precision="bf16x3", with_pose=True, warmup=3, forked="auto", burst=8,
-                 keep_pyramid=False, capture_error_mode=None):
+                 keep_pyramid=False, capture_error_mode=None, keep_both=False):
         self.model = model.eval()
         self.precision, self.with_pose, self.keep_pyramid = precision, with_pose, keep_pyramid
         self.static_in = {k: v.clone() for k, v in example_inputs.items() if torch.is_tensor(v)}
@@ -129,6 +130,10 @@ class GraphedPipeline:
                                                "step: %r" % (self.check["forked"],))
         self.graph = self.graphs[self.form]
         self.static_out = self.outs[self.form]
+        if not keep_both:                                            # the capture that lost keeps its private memory pool (activations of a
+            for f in [f for f in self.graphs if f != self.form]:     # whole step): drop it unless the caller wants to time both (bench.py)
+                del self.graphs[f], self.outs[f]
+                self.pools.pop(f, None)
 
     # -- construction helpers ---------------------------------------------------------------------------------------------
     def _step(self):

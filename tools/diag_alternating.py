@@ -36,7 +36,7 @@ with torch.no_grad():
         o = infer.pipeline_step(model, d, with_pose=False, keep_pyramid=True)
         eager.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
     torch.cuda.synchronize()
-    gp = infer.GraphedPipeline(model, batches[0], with_pose=False, keep_pyramid=True, forked="auto")
+    gp = infer.GraphedPipeline(model, batches[0], with_pose=False, keep_pyramid=True, forked="auto", keep_both=True)
 print("form kept by GraphedPipeline:", gp.form, gp.check)
 if "forked" not in gp.graphs:
     # the constant-input check already failed: drive the forked capture anyway to see what alternating inputs show
