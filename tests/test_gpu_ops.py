@@ -98,6 +98,50 @@ def test_knn_cell_list_search_equals_oracle(ops, case):
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
 
 
+@pytest.mark.parametrize("case", ["s512", "s128", "s64", "s1024", "sheet", "dups", "line", "point", "outside", "holes"])
+def test_knn1_through_job_table_equals_oracle(ops, case):
+    """K = 1 searches through ops.knn_jobs (the pyramid's path: job table + workspace) return the oracle's neighbour -- lowest index
+    among equal distances -- on uniform clouds of 64 .. 1024 points, a thin depth sheet queried from its own pixel grid, exact
+    duplicates, a degenerate axis, one repeated point, queries far outside the support's box and supports with points at the origin.
+    (Written for a cell-list form of the K = 1 search, round 4: exact, but one query per lane walking its own cells is latency-bound --
+    147 us against the exhaustive kernel's 73 us per pyramid -- so the exhaustive kernel stays; the cases stay as its test.)"""
+    from oracle import knn as oknn
+    rs = np.random.RandomState(abs(hash("k1" + case)) % (2 ** 31))
+    B, S, Q = 2, 512, 5000
+    qry = None
+    if case in ("s512", "s128", "s64", "s1024"):
+        S = int(case[1:])
+        sup = rs.rand(B, S, 3).astype(np.float32)
+    elif case == "sheet":
+        g = np.stack(np.meshgrid(np.linspace(-0.15, 0.15, 64), np.linspace(-0.15, 0.15, 64)), -1).reshape(-1, 2).astype(np.float32)
+        z = (0.8 + 0.05 * np.sin(7 * g[:, :1]) * np.cos(5 * g[:, 1:])).astype(np.float32)
+        grid = np.concatenate([g * z / 0.8, z], axis=1)
+        qry = np.stack([grid, grid[::-1].copy()])
+        sup = np.stack([grid[rs.permutation(4096)[:S]] for _ in range(B)])
+    elif case == "dups":
+        base = rs.rand(B, 300, 3).astype(np.float32)
+        sup = np.concatenate([base, base[:, :212]], axis=1)
+        qry = np.concatenate([sup, rs.rand(B, 2000, 3).astype(np.float32)], axis=1)
+    elif case == "line":
+        sup = rs.rand(B, S, 3).astype(np.float32)
+        sup[..., 0] = -0.5
+    elif case == "point":
+        sup = np.tile(np.float32([[0.3, 0.3, 0.3]]), (B, S, 1))
+    elif case == "outside":
+        sup = rs.rand(B, S, 3).astype(np.float32)
+        qry = (rs.rand(B, Q, 3) * 8 - 4).astype(np.float32)
+    else:
+        sup = rs.rand(B, S, 3).astype(np.float32) + np.float32([0, 0, 0.5])
+        sup[:, rs.rand(S) < 0.15] = 0.0
+    if qry is None:
+        qry = rs.rand(B, Q, 3).astype(np.float32)
+    qry = np.ascontiguousarray(qry, dtype=np.float32)
+    want = oknn.knn_batch(sup, qry, 1)
+    (got,) = ops.knn_jobs([(torch.from_numpy(np.ascontiguousarray(sup)).cuda(), torch.from_numpy(qry).cuda(), 1)], B)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+
+
 def test_knn_reference_parity_tie_free(ops):
     """Against the REAL reference (nanoflann, oracle/_ref) when its build travelled with the snapshot."""
     from oracle import knn as oknn
