@@ -67,8 +67,10 @@ typedef struct gdm_knn_job {
 #define GDM_KNN_MAX_JOBS 32
 int gdm_knn_jobs_hip(const gdm_knn_job* jobs /* host array */, int njobs, int B, void* stream);
 /* Same, with a device workspace (16-byte aligned, >= gdm_knn_jobs_workspace_bytes) in which every distinct support set of the
- * K > 1 jobs is re-laid out once as hashed float4 tiles that the search blocks stream with coalesced loads; without it
- * (gdm_knn_jobs_hip) each block gathers its tiles from the [S,3] array.  Results are identical.                                */
+ * K > 1 jobs is re-laid out once: small unorganised supports as hashed float4 tiles that the search blocks stream with coalesced
+ * loads, unorganised supports of >= 1024 points as (x, y) cell lists (a counting sort per crop; a query then visits cells ring by
+ * ring instead of every point), organised supports (grid_w) as per-column / per-row ratio ranges; without it (gdm_knn_jobs_hip)
+ * each block gathers its tiles from the [S,3] array.  Results are identical in every form, for any data.                       */
 size_t gdm_knn_jobs_workspace_bytes(const gdm_knn_job* jobs, int njobs, int B);
 int gdm_knn_jobs_ws_hip(const gdm_knn_job* jobs, int njobs, int B, void* workspace, size_t workspace_bytes, void* stream);
 
