@@ -285,10 +285,14 @@ typedef __attribute__((ext_vector_type(4))) float pw_f32x4;
 // texture path what a dwordx4 one does: 2 load instructions per step instead of 5), and the four blocks' results for one (row group,
 // r) are four consecutive points = one 16-byte store
 // one tile of 64 points x 16 channels (points from p0, channels from c0) by the KS waves of the workgroup; `red`: [KS][16][64] floats of LDS
-template <int KS, bool VEC>
+// CB: 16-channel blocks per wave (KS == 1 only).  With CB = 4 a wave forms 64 points x 64 channels from ONE pass over its x rows (the
+// training-size layers, ~100 k ... 1.5 M points: with one block per wave every x row was fetched Cout / 16 times); each accumulator
+// still sums its K rows in the same order, so the results do not depend on CB.
+template <int KS, bool VEC, int CB = 1>
 __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, const int c0, float (*red)[16][64])
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    static_assert(CB == 1 || KS == 1, "several channel blocks per wave only without a K split");
+    const int tid = threadIdx.x, wave = KS > 1 ? tid >> 6 : 0, lane = tid & 63;       // wave = this wave's part of the K axis
     const int l16 = lane & 15, kq = lane >> 4;
     const int n = a.n, Cout = a.Cout, K = a.K;
     const int kpart = (((K + KS - 1) / KS + 3) / 4) * 4;
@@ -307,13 +311,17 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
         pb[g] = p / n;
         pi[g] = (int)(p - pb[g] * n);
     }
-    const int wcol = min(c0 + l16, Cout - 1);
+    long wcoff[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) wcoff[cb] = (long)min(c0 + 16 * cb + l16, Cout - 1) * a.wcs;
 
-    pw_f32x4 acc[4];
+    pw_f32x4 acc[CB][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[cb][g][r] = 0.f;
 
     int seg_start = 0;
 #pragma unroll
@@ -332,17 +340,18 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                 if (sidx) col = min(max(sidx[pg[g]], 0), sn - 1);
                 xp[g] = sx + (pb[g] * sC + (k0 - seg_start + kq)) * (long)sn + col;
             }
-            const float* wp = a.wt + (long)(k0 + kq) * a.wks + (long)wcol * a.wcs;
+            const float* wp = a.wt + (long)(k0 + kq) * a.wks;
             const long xinc = 4L * sn, winc = 4L * a.wks;
             const int nfull = (k1 - k0) / 4;                               // steps whose four rows all lie inside [k0, k1)
             // software pipeline in groups of four steps: group i + 1's 20 loads are issued BEFORE group i's 16 MFMAs (two register
             // sets, the loop unrolled by two so that both are statically indexed)
             const int ngrp = nfull / 4;
-            float xa[4][4], wa[4], xb[4][4], wb[4];
-            auto load_grp = [&](float (&xv)[4][4], float (&wv)[4]) {
+            float xa[4][4], wa[4][CB], xb[4][4], wb[4][CB];
+            auto load_grp = [&](float (&xv)[4][4], float (&wv)[4][CB]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    wv[u] = wp[0];
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) wv[u][cb] = wp[wcoff[cb]];
                     wp += winc;
                     if (VEC) {
                         const float4 t = *reinterpret_cast<const float4*>(xp[0]);
@@ -357,11 +366,13 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                     }
                 }
             };
-            auto mfma_grp = [&](const float (&xv)[4][4], const float (&wv)[4]) {
+            auto mfma_grp = [&](const float (&xv)[4][4], const float (&wv)[4][CB]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][g], wv[u], acc[g], 0, 0, 0);
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][g], wv[u][cb], acc[cb][g], 0, 0, 0);
             };
             int st = 4 * ngrp;
             if (ngrp > 0) {
@@ -382,7 +393,9 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                 }
             }
             for (; st < nfull; ++st) {
-                const float wv = wp[0];
+                float wv[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) wv[cb] = wp[wcoff[cb]];
                 wp += winc;
                 float xv[4];
                 if (VEC) {
@@ -397,13 +410,19 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[g], wv, acc[g], 0, 0, 0);
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[g], wv[cb], acc[cb][g], 0, 0, 0);
             }
             if (k0 + 4 * nfull < k1) {                                      // the last, partial step: rows past k1 contribute zero
                 const bool in = k0 + 4 * nfull + kq < k1;
                 const long back = in ? 0 : (long)(k0 + 4 * nfull + kq - (k1 - 1));      // out-of-range lanes re-read row k1 - 1
-                const float wraw = wp[-back * a.wks];
-                const float wv = in ? wraw : 0.f;
+                float wv[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const float wraw = wp[wcoff[cb] - back * a.wks];
+                    wv[cb] = in ? wraw : 0.f;
+                }
                 float xraw[4];
                 if (VEC) {
                     const float4 t = *reinterpret_cast<const float4*>(xp[0] - back * sn);
@@ -413,7 +432,9 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
                     for (int g = 0; g < 4; ++g) xraw[g] = xp[g][-back * sn];
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? xraw[g] : 0.f, wv, acc[g], 0, 0, 0);
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? xraw[g] : 0.f, wv[cb], acc[cb][g], 0, 0, 0);
             }
         }
         seg_start = seg_end;
@@ -424,7 +445,7 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[g][r];
+                for (int r = 0; r < 4; ++r) red[wave][g * 4 + r][lane] = acc[0][g][r];
         }
         __syncthreads();
         if (wave != 0) return;
@@ -432,11 +453,13 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[g][r] += red[w][g * 4 + r][lane];
+                for (int r = 0; r < 4; ++r) acc[0][g][r] += red[w][g * 4 + r][lane];
     }
 
-    const int co = c0 + l16;
-    if (co >= Cout) return;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+    const int co = c0 + 16 * cb + l16;
+    if (co >= Cout) continue;
     const float sc = a.scale ? a.scale[co] : 1.f, sh = a.shift ? a.shift[co] : 0.f;
     auto finish = [&](float y) {
         y = fmaf(y, sc, sh);
@@ -449,7 +472,7 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
     for (int j = 0; j < 4; ++j) {
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = finish(VEC ? acc[i][j] : acc[j][i]);
+        for (int i = 0; i < 4; ++i) v[i] = finish(VEC ? acc[cb][i][j] : acc[cb][j][i]);
         const long q0 = p0 + (VEC ? 16 * kq + 4 * j : 16 * j + 4 * kq);   // first of the four consecutive points
         if (a.point_major) {
 #pragma unroll
@@ -468,13 +491,27 @@ __device__ __forceinline__ void pw_mfma_tile(const PwArgs& a, const long p0, con
             }
         }
     }
+    }
 }
 
-template <int KS, bool VEC>
+template <int KS, bool VEC, int CB = 1>
 __global__ __launch_bounds__(KS * 64) void pointwise_mfma_kernel(const PwArgs a)
 {
     __shared__ __attribute__((aligned(16))) float red[KS > 1 ? KS : 1][16][64];
-    pw_mfma_tile<KS, VEC>(a, (long)blockIdx.x * PT, (int)blockIdx.y * 16, red);
+    pw_mfma_tile<KS, VEC, CB>(a, (long)blockIdx.x * PT, (int)blockIdx.y * (16 * CB), red);
+}
+
+// No K split, the workgroup's FOUR waves = four channel groups (of 16 CB channels) of ONE 64-point tile: the training-size layers
+// (~100 k ... 1.5 M points per launch, 32 ... 256 channels).  With one-wave workgroups the channel groups of a tile were separate
+// workgroups far apart in dispatch order and every x row came from HBM Cout / 16 times; here the four waves ask for the same x rows at
+// about the same time, through the same L1.  Same sums in the same order as every other form.
+template <bool VEC, int CB>
+__global__ __launch_bounds__(256) void pointwise_mfma_cw_kernel(const PwArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int c0 = ((int)blockIdx.y * 4 + wave) * (16 * CB);
+    if (c0 >= a.Cout) return;
+    pw_mfma_tile<1, VEC, CB>(a, (long)blockIdx.x * PT, c0, nullptr);
 }
 
 // Up to four INDEPENDENT layers of equal K and Cout in one launch (the four prior products M_k . pool_k(f) of the pyramid-pooling
@@ -636,6 +673,16 @@ extern "C" int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float*
             if (mvec) hipLaunchKernelGGL((pointwise_mfma_kernel<KSV, true>), grid, dim3(KSV * 64), 0, st, a);            \
             else hipLaunchKernelGGL((pointwise_mfma_kernel<KSV, false>), grid, dim3(KSV * 64), 0, st, a);                \
         } while (0)
+        // no K split and still >= 2048 workgroups with four (two) channel blocks per wave: each x row is then fetched Cout / 64 (/ 32)
+        // times instead of Cout / 16
+        if (ks == 1 && Cout >= 32 && tiles >= 1024) {
+            // training sizes (B = 24: 64 -> 64 channels at 393 k points 95 -> 52 us, 576 -> 64 755 -> 430 us; two channel blocks per wave
+            // measured equal): tools/bench_pointwise_train.py
+            const dim3 gridc((unsigned)tiles, gdm_cdiv(Cout, 64));
+            if (mvec) hipLaunchKernelGGL((pointwise_mfma_cw_kernel<true, 1>), gridc, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((pointwise_mfma_cw_kernel<false, 1>), gridc, dim3(256), 0, st, a);
+            return gdm_launch_status("pointwise_mfma_cw_kernel");
+        }
         if (ks == 1) GDM_PWM(1);
         else if (ks == 2) GDM_PWM(2);
         else if (ks == 4) GDM_PWM(4);

@@ -786,6 +786,10 @@ def test_affine_relu_maxpool_equals_modules(ops, B, C, H, W):
     (1, 4, (64, 64), 48, None, False),                #   16-byte operand loads of the out-of-range lanes must stay inside the array
     (4, 512, (64,), 64, None, True),                  # point-major product for the 64-channel fusion kernel
     (2, 130, (70,), 130, None, True),
+    (8, 16384, (32,), 64, None, False),               # training-size layers: no K split, the four waves = four channel groups of a tile
+    (8, 16384, (32,), 32, None, False),               # ... two of the four waves have channels
+    (4, 32770, (40,), 72, None, False),               # ... ragged: n % 4 != 0, the second 64-channel group holds 8 valid channels
+    (2, 65536, (16, 16), 80, 4096, False),            # ... an indexed segment, 80 = 64 + 16 channels
 ])
 def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, pm):
     """ops.pointwise (gdm_pointwise_hip) == cat -> 1x1 conv -> affine (folded BN) -> activation in fp64 torch, to fp32 rounding
@@ -822,6 +826,23 @@ def test_pointwise_layer_vs_torch(ops, B, n, cs, cout, n_src, pm):
     plain = ops.pointwise(segs, w.t().contiguous(), point_major=pm)
     want = torch.einsum("ok,bkn->bon", w.double(), torch.cat(xs, 1).double())
     assert ((plain.transpose(1, 2) if pm else plain).double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,n,K,cout", [(8, 16384, 32, 64), (4, 4096, 64, 128), (24, 64, 256, 512), (2, 1000, 9, 8), (3, 4098, 128, 64)])
+def test_pointwise_rowmajor_weight_equals_transposed_copy(ops, B, n, K, cout):
+    """w_rowmajor=True reads the weight as nn.Conv holds it ([Cout, K], the training path) -- the same sums in the same order as the
+    [K, Cout] copy on the MFMA form (K >= 32: bit-identical); the FMA form to fp32 rounding."""
+    g = torch.Generator(device="cpu").manual_seed(n + K)
+    x = torch.randn(B, K, n, generator=g).cuda()
+    w = (torch.randn(cout, K, generator=g) / K ** 0.5).cuda()
+    a = ops.pointwise([x], w, w_rowmajor=True)
+    b = ops.pointwise([x], w.t().contiguous())
+    if K >= 32:
+        assert torch.equal(a, b)
+    else:
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+    want = torch.einsum("ok,bkn->bon", w.double(), x.double())
+    assert (a.double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
 
 
 def test_dilated_res_block_tail_as_one_layer_equals_modules():
