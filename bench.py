@@ -56,6 +56,10 @@ def parse(argv=None):
     ap.add_argument("--strict", action="store_true", help="exit 3 (after printing the line) if the hipGraph replay fails its check against the eager step")
     ap.add_argument("--no-forked", action="store_true", help="capture the single-stream hipGraph form only (infer.GraphedPipeline(forked=False))")
     ap.add_argument("--no-heavy-extras", action="store_true", help="skip the legs that run after the JSON line (DGCNN variant, training step)")
+    ap.add_argument("--group-of-one", action="store_true",
+                    help="rehearsal on a 1-GPU box: join a process group (--backend) although there is one rank, so that the RCCL "
+                         "initialisation, the device all-reduces, the barriers and the captures beside the backend's helper threads "
+                         "all run exactly as they do with N ranks")
     ap.add_argument("--probe-ranks", action="store_true",
                     help="launcher self-test: every rank joins the process group, all-reduces a 1 and rank 0 prints the count; no GPU work")
     return ap.parse_args(argv)
@@ -558,7 +562,14 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n_ranks_seen, backend_info = 1, None
-    if world > 1:
+    grouped = world > 1 or args.group_of_one
+    if grouped:
+        if world == 1 and "MASTER_ADDR" not in os.environ:       # --group-of-one without a launcher: a rendezvous of this process alone
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -622,7 +633,7 @@ def main(argv=None):
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -655,7 +666,7 @@ def main(argv=None):
             try:
                 gp = infer.GraphedPipeline(model, inputs, precision=prec_name, with_pose=False, keep_pyramid=True,
                                            forked=False if args.no_forked else "auto", keep_both=True,
-                                           capture_error_mode="thread_local" if world > 1 else None)
+                                           capture_error_mode="thread_local" if grouped else None)
                 product_check = dict(gp.check, form=gp.form)
                 for form in gp.graphs:
                     gp.replay(form)
@@ -709,7 +720,7 @@ def main(argv=None):
     # the forms are compared on their MAX over ranks (each form was timed by all ranks at once); a form some rank could not offer is out
     INF = float("inf")
     forms = [dts["forked"] if dts["forked"] is not None else INF, dts["single"] if dts["single"] is not None else INF, dt_eager]
-    if world > 1:
+    if grouped:
         t = torch.tensor(forms, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         forms = [float(v) for v in t.tolist()]
@@ -720,7 +731,7 @@ def main(argv=None):
     launch = ("infer.GraphedPipeline default: hipGraph replay, FORKED form (pyramid / mesh branch / point branch on side streams), kept because bit-identical to the single-stream eager step before and after the timed replays",
               "infer.GraphedPipeline: hipGraph replay, single-stream form (the forked form was not offered or failed its bit-identity check on some rank)",
               "eager loop of infer.pipeline_step (one host call per kernel; no valid hipGraph capture, or --eager)")[which]
-    if world > 1:
+    if grouped:
         # every rank's check rides along: one rank outside tolerance is reported, it does not stop the others
         bad = 0.0 if all((c is None or c.get("ok")) for c in checks.values()) else 1.0
         flag = torch.tensor([bad], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -863,7 +874,7 @@ def main(argv=None):
                 json.dump({"headline": line, "extras_after_line": heavy}, f, indent=1)
         except OSError:
             pass
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     if args.strict and ranks_outside:
         sys.exit(3)                                            # --strict: the exit code also says a replay was outside tolerance
