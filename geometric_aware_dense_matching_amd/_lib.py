@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdm_labelstat_idx_hip": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gdm_group_gather_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_group_gather_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gdm_group_gather_bwd2_hip": (_i, [_vp, ctypes.c_long, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_gather_max_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gdm_gather_max_bwd_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_gather_nn_hip": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -115,6 +116,7 @@ SIGNATURES = {
     "gdm_psp_pools_bwd_hip": (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _i, _vp, _vp]),
     "gdm_conv1x1_weight_bytes": (_sz, [_i, _i]),
     "gdm_conv1x1_pack_weight_hip": (_i, [_vp, _i, _i, _vp, _vp]),
+    "gdm_conv_pack_weight_dgrad_hip": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gdm_conv1x1_packed_hip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gdm_depth_to_xyz_hip": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gdm_spline_aggregate_hip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

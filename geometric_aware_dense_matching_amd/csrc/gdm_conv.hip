@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void conv_pack_act_kernel(const float* __restr
 
 // w f32[Cout,Cin,3,3] -> rows ((tap*nchunk + chunk)*CoutP + co): channels [128 chunk, +128) of tap (ky,kx); CoutP = Cout rounded
 // up to 128, rows co >= Cout are zero (a workgroup always stages 128 rows)
-__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, unsigned char* __restrict__ out)
+// dgrad: w is the FORWARD weight f32[Cin, Cout, taps] of the layer whose input gradient is wanted; the rows written are those of the
+// flipped, transposed filter w'[co][ci][tap] = w[ci][co][taps - 1 - tap] (the input gradient of a 3x3/s1/p1 or 1x1 convolution is the same
+// convolution of grad_out with w') -- no flip / transpose / contiguous copies in front of the pack.
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, unsigned char* __restrict__ out,
+                                                          int dgrad = 0)
 {
     const int nchunk = (Cin + 127) / 128;
     const int CoutP = (Cout + 127) & ~127;
@@ -100,7 +104,11 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
     const int chunk = tc % nchunk, tap = tc / nchunk;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (co < Cout && chunk * 128 + ch * 8 + j < Cin) ? w[((long)co * Cin + chunk * 128 + ch * 8 + j) * taps + tap] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int ci = chunk * 128 + ch * 8 + j;
+        const bool in = co < Cout && ci < Cin;
+        v[j] = !in ? 0.f : dgrad ? w[((long)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((long)co * Cin + ci) * taps + tap];
+    }
     unsigned hi[4], lo[4];
     split8(v, hi, lo);
     unsigned char* r = out + row * ROWB;
@@ -805,13 +813,22 @@ extern "C" size_t gdm_conv1x1_weight_bytes(int Cout, int Cin)
     return (size_t)((Cin + 127) / 128) * ((Cout + 127) & ~127) * ROWB;
 }
 
-static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who)
+static int pack_weight(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream, const char* who, int dgrad = 0)
 {
     GDM_CHECK_ARG(w && wpk, "%s: NULL pointer", who);
     GDM_CHECK_ARG(Cout >= 1 && cin_ok(Cin), "%s: Cout=%d Cin=%d (Cin a multiple of 128, or 64)", who, Cout, Cin);
     const long items = (long)taps * ((Cin + 127) / 128) * ((Cout + 127) & ~127) * 16;
-    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk);
+    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(gdm_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, (unsigned char*)wpk, dgrad);
     return gdm_launch_status("conv_pack_w_kernel");
+}
+
+// The packed weights of the INPUT-GRADIENT convolution straight from the forward weight w f32[Cout, Cin, taps] (taps 9 or 1): the packed
+// layer has Cin output channels and Cout input channels (Cout a multiple of 128, or 64); wpk: gdm_conv3x3_weight_bytes(Cin, Cout) /
+// gdm_conv1x1_weight_bytes(Cin, Cout) bytes.
+extern "C" int gdm_conv_pack_weight_dgrad_hip(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream)
+{
+    GDM_CHECK_ARG(taps == 9 || taps == 1, "gdm_conv_pack_weight_dgrad_hip: taps=%d (9 or 1)", taps);
+    return pack_weight(w, Cin, Cout, taps, wpk, stream, "gdm_conv_pack_weight_dgrad_hip", 1);
 }
 
 extern "C" int gdm_conv3x3_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream)

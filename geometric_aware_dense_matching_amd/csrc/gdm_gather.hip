@@ -38,8 +38,9 @@ __global__ __launch_bounds__(GB) void group_gather_kernel(const float* __restric
     }
 }
 
+// gbs: floats between two batch items of go (C * mk when go is dense; larger for a channel slice of a wider tensor)
 __global__ __launch_bounds__(GB) void group_gather_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
-                                                              int C, int n, long mk, float* __restrict__ gfeat)
+                                                              int C, int n, long mk, float* __restrict__ gfeat, long gbs)
 {
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * CCHUNK;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(GB) void group_gather_bwd_kernel(const float* __res
     const int cend = min(c0 + CCHUNK, C);
     for (int c = c0; c < cend; ++c) {
         const long row = (long)b * C + c;
-        atomicAdd(&gfeat[row * n + src], go[row * mk + e]);
+        atomicAdd(&gfeat[row * n + src], go[(long)b * gbs + (long)c * mk + e]);
     }
 }
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(GB) void gather_max_bwd_kernel(const float* __restr
 constexpr int LCH = 4;
 template <bool VEC>
 __global__ __launch_bounds__(GB) void group_gather_bwd_lds_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx,
-                                                                  int C, int n, long mk, long seg_len, float* __restrict__ gfeat)
+                                                                  int C, int n, long mk, long seg_len, float* __restrict__ gfeat, long gbs)
 {
     extern __shared__ float accs[];                     // [LCH][n]
     const int b = blockIdx.z;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(GB) void group_gather_bwd_lds_kernel(const float* _
             float4 g[LCH];
 #pragma unroll
             for (int c = 0; c < LCH; ++c)
-                g[c] = c < nc ? *reinterpret_cast<const float4*>(go + ((long)b * C + c0 + c) * mk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[c] = c < nc ? *reinterpret_cast<const float4*>(go + (long)b * gbs + (long)(c0 + c) * mk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
             const int s0 = min(max(s4.x, 0), n - 1), s1 = min(max(s4.y, 0), n - 1), s2 = min(max(s4.z, 0), n - 1), s3 = min(max(s4.w, 0), n - 1);
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(GB) void group_gather_bwd_lds_kernel(const float* _
         for (long e = e0 + threadIdx.x; e < e1; e += GB) {
             int src = idx[(long)b * mk + e];
             src = min(max(src, 0), n - 1);
-            for (int c = 0; c < nc; ++c) atomicAdd(&accs[c * n + src], go[((long)b * C + c0 + c) * mk + e]);
+            for (int c = 0; c < nc; ++c) atomicAdd(&accs[c * n + src], go[(long)b * gbs + (long)(c0 + c) * mk + e]);
         }
     }
     __syncthreads();
@@ -450,11 +451,24 @@ extern "C" int gdm_group_gather_hip(const float* feat, const int32_t* idx, int B
     return gdm_launch_status("group_gather_kernel");
 }
 
+extern "C" int gdm_group_gather_bwd2_hip(const float* go, long go_bstride, const int32_t* idx, int B, int C, int n, int m, int K,
+                                         float* gfeat, void* stream);
+
 extern "C" int gdm_group_gather_bwd_hip(const float* go, const int32_t* idx, int B, int C, int n, int m, int K,
                                         float* gfeat, void* stream)
 {
+    return gdm_group_gather_bwd2_hip(go, (long)C * m * K, idx, B, C, n, m, K, gfeat, stream);
+}
+
+// go_bstride: floats between two batch items of go (rows of m * K floats, channel stride m * K): a channel slice of a concatenation's
+// gradient is read in place
+extern "C" int gdm_group_gather_bwd2_hip(const float* go, long go_bstride, const int32_t* idx, int B, int C, int n, int m, int K,
+                                         float* gfeat, void* stream)
+{
     GDM_CHECK_ARG(go && idx && gfeat, "gdm_group_gather_bwd_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && C >= 1 && n >= 1 && m >= 1 && K >= 1, "gdm_group_gather_bwd_hip: bad shape");
+    GDM_CHECK_ARG(go_bstride >= (long)C * m * K, "gdm_group_gather_bwd_hip: batch stride %ld below C*m*K", go_bstride);
+    const long gbs = go_bstride;
     const long mk = (long)m * K;
     if ((size_t)n * LCH * sizeof(float) <= 64 * 1024 && mk >= 4L * n && gdm_cdiv(C, LCH) <= 65535 && B <= 65535) {
         // contended: privatise in LDS; segments sized so that a block scans >= 8 entries per accumulator it later flushes
@@ -463,18 +477,18 @@ extern "C" int gdm_group_gather_bwd_hip(const float* go, const int32_t* idx, int
         long nseg = gdm_cdiv(mk, seg_len);
         if (nseg > 65535) { nseg = 65535; seg_len = gdm_cdiv(mk, nseg); }
         dim3 grid((unsigned)nseg, gdm_cdiv(C, LCH), B);
-        const bool vec = mk % 4 == 0 && seg_len % 4 == 0 && (((uintptr_t)go | (uintptr_t)idx) & 15) == 0;
+        const bool vec = mk % 4 == 0 && seg_len % 4 == 0 && gbs % 4 == 0 && (((uintptr_t)go | (uintptr_t)idx) & 15) == 0;
         if (vec)
             hipLaunchKernelGGL(group_gather_bwd_lds_kernel<true>, grid, dim3(GB), (size_t)n * LCH * sizeof(float), STREAM(stream), go, idx, C, n,
-                               mk, seg_len, gfeat);
+                               mk, seg_len, gfeat, gbs);
         else
             hipLaunchKernelGGL(group_gather_bwd_lds_kernel<false>, grid, dim3(GB), (size_t)n * LCH * sizeof(float), STREAM(stream), go, idx, C, n,
-                               mk, seg_len, gfeat);
+                               mk, seg_len, gfeat, gbs);
         return gdm_launch_status("group_gather_bwd_lds_kernel");
     }
     dim3 grid(gdm_cdiv(mk, GB), gdm_cdiv(C, CCHUNK), B);
     GDM_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gdm_group_gather_bwd_hip: grid too large");
-    hipLaunchKernelGGL(group_gather_bwd_kernel, grid, dim3(GB), 0, STREAM(stream), go, idx, C, n, mk, gfeat);
+    hipLaunchKernelGGL(group_gather_bwd_kernel, grid, dim3(GB), 0, STREAM(stream), go, idx, C, n, mk, gfeat, gbs);
     return gdm_launch_status("group_gather_bwd_kernel");
 }
 

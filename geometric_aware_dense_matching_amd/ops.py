@@ -269,10 +269,12 @@ class _GroupGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         (idx,) = ctx.saved_tensors
-        go = go.contiguous()
         B, C, m, K = go.shape
+        # a channel slice of a concatenation's gradient (dense rows, a larger batch stride) is read where it lies
+        if not (go.dtype == torch.float32 and go.stride(3) == 1 and go.stride(2) == K and go.stride(1) == m * K and go.stride(0) >= C * m * K):
+            go = go.contiguous()
         g = torch.zeros((B, C, ctx.n), dtype=torch.float32, device=go.device)
-        check(_lib.lib().gdm_group_gather_bwd_hip(go.data_ptr(), idx.data_ptr(), B, C, ctx.n, m, K, g.data_ptr(), _stream()),
+        check(_lib.lib().gdm_group_gather_bwd2_hip(go.data_ptr(), go.stride(0), idx.data_ptr(), B, C, ctx.n, m, K, g.data_ptr(), _stream()),
               "gdm_group_gather_bwd_hip")
         return g, None
 
@@ -1044,7 +1046,7 @@ class _WxTrain(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if x3.is_cuda and _gemm_fwd_mfma_ok(Cout, Cin, n, B):
-                gx = gemm_bf16x3(go, gemm_pack_weight(w2.t().contiguous()), Cin)
+                gx = gemm_bf16x3(go, conv_pack_weight_dgrad(w2), Cin)
             elif settings.USE_POINTWISE_TRAIN and x3.is_cuda:
                 gx = pointwise([go], w2)
             else:
@@ -1550,6 +1552,19 @@ def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1))
             and (cin == 64 or cin % 128 == 0) and weight.shape[0] % 8 == 0 and x.shape[0] <= 65535)
 
 
+def conv_pack_weight_dgrad(weight):
+    """The packed weights of the input-gradient convolution of a 3x3/s1/p1 (w f32[Cout,Cin,3,3]) or 1x1 (w f32[Cout,Cin]) layer, straight
+    from the forward weight: one launch instead of flip + transpose + contiguous + pack (include/gdm.h gdm_conv_pack_weight_dgrad_hip)."""
+    weight = _dev(weight.detach(), torch.float32, "weight")
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    taps = 9 if weight.dim() == 4 else 1
+    L = _lib.lib()
+    nbytes = L.gdm_conv3x3_weight_bytes(Cin, Cout) if taps == 9 else L.gdm_conv1x1_weight_bytes(Cin, Cout)
+    wpk = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    check(L.gdm_conv_pack_weight_dgrad_hip(weight.data_ptr(), Cout, Cin, taps, wpk.data_ptr(), _stream()), "gdm_conv_pack_weight_dgrad_hip")
+    return wpk
+
+
 def conv3x3_pack_weight(weight):
     """w f32[Cout,Cin,3,3] -> packed split-bf16 rows (u8 tensor); cache it per weight version."""
     weight = _dev(weight.detach(), torch.float32, "weight")
@@ -1659,8 +1674,7 @@ class _Conv3x3Train(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             # dgrad of a 3x3/s1/p1 convolution = the same convolution of grad_out with the flipped, transposed filter
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
-            gx = conv3x3_bf16x3(go, conv3x3_pack_weight(wt), weight.shape[1])
+            gx = conv3x3_bf16x3(go, conv_pack_weight_dgrad(weight), weight.shape[1])
         if ctx.needs_input_grad[1]:
             if conv3x3_wgrad_supported(x, go):
                 gw = conv3x3_wgrad(x, go)

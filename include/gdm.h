@@ -111,6 +111,10 @@ int gdm_group_gather_hip(const float* feat, const int32_t* idx, int B, int C, in
 /* grad_feat[b,c,idx[b,j,k]] += grad_out[b,c,j,k]; grad_feat must be zeroed by the caller. */
 int gdm_group_gather_bwd_hip(const float* grad_out, const int32_t* idx, int B, int C, int n, int m, int K,
                              float* grad_feat, void* stream);
+/* the same with grad_out read in place from a wider tensor: go_bstride = floats between two batch items (rows of m*K floats, channel
+ * stride m*K; >= C*m*K) -- the gradient slice a torch.cat backward hands to nearest_interpolation (models/ffb6d.py:148-163) */
+int gdm_group_gather_bwd2_hip(const float* grad_out, long go_bstride, const int32_t* idx, int B, int C, int n, int m, int K,
+                              float* grad_feat, void* stream);
 
 /* out[b,c,j] = max_k feat[b,c,idx[b,j,k]]; arg i32[B,C,m] (may be NULL) = winning source index.
  * replaces FFB6DEmb.random_sample (models/ffb6d.py:128-146).                             */
@@ -457,6 +461,11 @@ int gdm_psp_pools_bwd_hip(const float* g1, const float* g2, const float* g3, con
  * arbitrary: the packed weights carry zero rows up to the next multiple of 128 and the extra outputs are never stored. */
 size_t gdm_conv1x1_weight_bytes(int Cout, int Cin);
 int gdm_conv1x1_pack_weight_hip(const float* w, int Cout, int Cin, void* wpk, void* stream);
+/* training: the packed weights of the INPUT-GRADIENT convolution (the flipped, transposed filter) straight from the forward weight
+ * w f32[Cout,Cin,taps], taps 9 (3x3/s1/p1) or 1: a layer with Cin outputs and Cout inputs (Cout % 128 == 0 or Cout == 64); wpk holds
+ * gdm_conv3x3_weight_bytes(Cin, Cout) / gdm_conv1x1_weight_bytes(Cin, Cout) bytes.  Replaces the flip / transpose / contiguous copies
+ * torch's convolution backward makes of the weights of models/cnn/extractors.py:36-58. */
+int gdm_conv_pack_weight_dgrad_hip(const float* w, int Cout, int Cin, int taps, void* wpk, void* stream);
 int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift,
                            int B, int Cin, int Cout, int H, int W, int act, int pixel_major, float* out, void* stream);
 

@@ -296,6 +296,39 @@ def test_att_pool(ops, B, C, n, K):
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)          # exp / summation order
 
 
+@pytest.mark.parametrize("B,C,n,m,K,extra", [(3, 8, 64, 1024, 1, 5), (2, 16, 256, 256, 16, 16), (2, 6, 50, 77, 1, 3)])
+def test_gather_backward_reads_a_channel_slice_in_place(ops, B, C, n, m, K, extra):
+    """The gradient a torch.cat backward hands to nearest_interpolation / group_gather is a channel slice of a wider tensor (dense rows,
+    larger batch stride): gdm_group_gather_bwd2_hip reads it where it lies -- same result as from a contiguous copy."""
+    g = torch.Generator(device="cpu").manual_seed(n + m)
+    feat = torch.randn(B, C, n, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, n, (B, m, K), generator=g).int().cuda()
+    wide = torch.randn(B, C + extra, m, K, generator=g).cuda()
+    go = wide[:, extra:]                                              # non-contiguous: batch stride (C + extra) m K
+    assert not go.is_contiguous()
+    y = ops.group_gather(feat, idx)
+    (ga,) = torch.autograd.grad(y, feat, go)
+    (gb,) = torch.autograd.grad(ops.group_gather(feat, idx), feat, go.contiguous())
+    want = torch.zeros(B, C, n, dtype=torch.float64, device="cuda")
+    want.scatter_add_(2, idx.long().view(B, 1, m * K).expand(B, C, m * K), go.reshape(B, C, m * K).double())
+    tol = 1e-5 * max(1.0, want.abs().max().item())
+    assert (ga.double() - want).abs().max().item() < tol and (gb.double() - want).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("Cout,Cin,taps", [(128, 256, 9), (64, 128, 9), (128, 200, 1), (512, 64, 1), (128, 128, 9), (256, 72, 9)])
+def test_dgrad_weight_pack_equals_pack_of_flipped_transposed_filter(ops, Cout, Cin, taps):
+    """gdm_conv_pack_weight_dgrad_hip(w) == pack(w.flip(2, 3).transpose(0, 1)) byte for byte (3x3), == pack(w.t()) (1x1)."""
+    g = torch.Generator(device="cpu").manual_seed(Cout + Cin + taps)
+    if taps == 9:
+        w = torch.randn(Cout, Cin, 3, 3, generator=g).cuda()
+        want = ops.conv3x3_pack_weight(w.flip(2, 3).transpose(0, 1).contiguous())
+    else:
+        w = torch.randn(Cout, Cin, generator=g).cuda()
+        want = ops.gemm_pack_weight(w.t().contiguous())
+    got = ops.conv_pack_weight_dgrad(w)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 def test_gather_backward_matches_autograd(ops):
     from oracle import ops_ref
     rs = np.random.RandomState(6)
