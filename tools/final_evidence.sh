@@ -26,4 +26,5 @@ python tools/summarize_trace.py $TT --steps 5 --periodic > $out/train_steady_b24
 find $out/proft -name "*.csv" -delete; find $out/proft -name "*.db" -delete
 echo "train profile done"
 python bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --no-heavy-extras > $out/two_rank.json 2> $out/two_rank.err || exit 3
+python bench.py --group-of-one --backend nccl --no-cpu-baseline --no-extras --steps 20 --warmup 3 > $out/rccl_group_of_one.json 2> $out/rccl_group_of_one.err || exit 8
 head -c 300 $out/bench_n1.json; echo; head -1 $out/steady_state_b16.csv; tail -1 $out/step_sequence.txt; tail -1 $out/forked_replay_queues.txt; head -1 $out/train_steady_b24.csv; head -c 200 $out/two_rank.json
