@@ -806,7 +806,7 @@ def _sync_group(bn):
     if not (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()):
         return None
     group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    return group if dist.get_world_size(group) > 1 else None
+    return group if dist.get_world_size(group) >= settings.SYNCBN_MIN_WORLD else None
 
 
 def bn_train_supported(x, bn):

@@ -79,6 +79,9 @@ PACK_MESH_ROWS = os.environ.get("GDM_PACK_MESH_ROWS", "1") != "0"         # with
 SIDE_PARTS = os.environ.get("GDM_SIDE_PARTS", "mesh,point,pyr").split(",")     # development: which branches are forked
 STATIC_MATCH_ROWS = _flag("GDM_STATIC_MATCH_ROWS", "0")
 UPCONV_MIN_CIN = int(os.environ.get("GDM_UPCONV_MIN_CIN", "0"))
+# ranks a SyncBatchNorm's group must span before its statistics are all-reduced (2: a group of one is plain BatchNorm).  1 sends a single
+# rank through the collective as well -- the RCCL rehearsal on a one-GPU box (tests/test_gpu_train.py)
+SYNCBN_MIN_WORLD = 2
 
 ALL_SWITCHES = ("USE_MFMA_CONV", "USE_MFMA_CONV_TRAIN", "USE_MFMA_GEMM", "USE_FUSED_UPCONV", "USE_LOWRES_UPCONV_TRAIN",
                 "USE_SPLIT_PSP_TRAIN", "USE_FUSED_LFA", "USE_GROUPED_SPLINE", "USE_FUSED_BN_TRAIN", "USE_FUSED_SYNCBN",

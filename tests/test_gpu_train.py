@@ -376,6 +376,68 @@ def test_fused_syncbatchnorm_two_ranks_equals_whole_batch_batchnorm():
     assert out.get() == "ok"
 
 
+def _rccl_group_of_one_worker(port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        from geometric_aware_dense_matching_amd import ops, train_lm
+        from geometric_aware_dense_matching_amd.geoMatch import GeoMatch
+        M, N, B = 512, 1024, 2
+        torch.manual_seed(0)
+        model = GeoMatch(make_model_cfg(n_mesh_node=M, num_points=N), 1, model_points=synthetic.make_model_points(1, M)).to(dev).train()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        ds = train_lm.SyntheticCrops(B, N, M, seed=5)
+        batch = torch.utils.data.default_collate([ds[i] for i in range(B)])
+
+        def run(m):
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(1)
+            o, _ = train_lm.model_fn_dec(m, batch, dev)
+            o["loss"].backward()
+            core = m.module if hasattr(m, "module") else m
+            return float(o["loss"].detach()), {k: p.grad.detach().double().clone() for k, p in core.named_parameters() if p.grad is not None}
+
+        l0, g0 = run(model)                                           # plain BatchNorm, no process group involved
+        sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        sync.load_state_dict(state)
+        n_sync = sum(isinstance(mod, torch.nn.SyncBatchNorm) for mod in sync.modules())
+        ddp = torch.nn.parallel.DistributedDataParallel(sync, device_ids=[0], output_device=0, find_unused_parameters=True)
+        settings.SYNCBN_MIN_WORLD = 1                                 # the single rank goes through the collective too
+        some_bn = next(mod for mod in sync.modules() if isinstance(mod, torch.nn.SyncBatchNorm))
+        assert ops._sync_group(some_bn) is not None and dist.get_backend(ops._sync_group(some_bn)) == "nccl"
+        l1, g1 = run(ddp)
+        den = sum((v ** 2).sum().item() for v in g0.values()) ** 0.5
+        d = sum(((g1[k] - g0[k]) ** 2).sum().item() for k in g0) ** 0.5 / den
+        out.put((l0, l1, d, n_sync, len(g0), set(g0) == set(g1), dist.get_backend()))
+    finally:
+        settings.SYNCBN_MIN_WORLD = 2
+        dist.destroy_process_group()
+
+
+def test_training_step_under_ddp_and_syncbn_in_an_rccl_group_of_one():
+    """RCCL on the card at hand: one rank joins an `nccl` process group, the model is converted to SyncBatchNorm and wrapped in
+    DistributedDataParallel as parallel.wrap_for_training does for N ranks (/root/reference/train_lm.py:412,436-439), and -- with
+    settings.SYNCBN_MIN_WORLD = 1 -- every fused BatchNorm sends its fp64 statistics through `dist.all_reduce` on the device in both
+    directions.  A group of one changes no number: loss and gradients equal the plain single-process step (same dropout seed)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_group_of_one_worker, args=(port, out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    l0, l1, d, n_sync, n_grads, same_keys, backend = out.get()
+    print("RCCL group of one: loss %.6f vs %.6f, gradient distance %.3e, %d SyncBatchNorm layers, %d gradients" % (l0, l1, d, n_sync, n_grads))
+    assert backend == "nccl" and n_sync > 80 and n_grads > 300 and same_keys
+    assert abs(l1 - l0) < 1e-5 * abs(l0) and d < 1e-3, (l0, l1, d)
+
+
 def test_training_step_through_fused_paths_equals_module_paths():
     """One whole training step (train-mode BatchNorm, dropout, fused circle loss) with the training-side kernel paths on == the same
     step with all of them switched back to the torch modules: loss, running statistics and parameter gradients.
