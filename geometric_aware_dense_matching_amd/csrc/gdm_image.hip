@@ -1197,8 +1197,14 @@ extern "C" int gdm_upconv3x3_gather_hip(const float* z, const float* scale, cons
         else hipLaunchKernelGGL(upconv3x3_gather_lds_kernel<2>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
         return gdm_launch_status("upconv3x3_gather_lds_kernel");
     }
+    // any other scale factor: the direct form (reads its taps from global memory).  (The three launch lines below were lost when the
+    // LDS form was added: the function then returned success without having written `out` -- unreachable from the model, whose
+    // stages all upsample x2, but wrong for a caller of the C entry point.  tests/test_gpu_ops.py covers a 16 -> 20 stage now.)
     const int quads = ((OW + 3) / 4) * OH;
     dim3 grid(gdm_cdiv(quads, 256), B * Cout);
+    if (act == 0) hipLaunchKernelGGL(upconv3x3_gather_kernel<0>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
+    else if (act == 1) hipLaunchKernelGGL(upconv3x3_gather_kernel<1>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
+    else hipLaunchKernelGGL(upconv3x3_gather_kernel<2>, grid, dim3(256), 0, s, z, scale, shift, Cout, H, W, OH, OW, rh, rw, slope, out);
     return gdm_launch_status("upconv3x3_gather_kernel");
 }
 

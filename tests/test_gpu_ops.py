@@ -527,6 +527,24 @@ def test_upconv3x3_gather_equals_conv_after_upsample(ops, B, Cin, Cout, H, W):
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,OH,OW", [(2, 8, 4, 16, 16, 20, 20), (1, 6, 5, 9, 12, 12, 31), (2, 4, 3, 8, 8, 8, 8)])
+def test_upconv3x3_gather_other_scale_factors(ops, B, Cin, Cout, H, W, OH, OW):
+    """Output sizes other than 2H x 2W (scale factors the LDS tile does not fit, incl. 1:1) take the direct kernel: conv3x3(pad 1) of the
+    align_corners bilinear resize + affine + ReLU == low-res 1x1 conv + 9-tap gather.  (The C entry point once returned success without
+    launching anything on this path.)"""
+    rs = np.random.RandomState(OH * 100 + OW)
+    x = torch.from_numpy(rs.randn(B, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(np.float32))
+    scale = torch.from_numpy((1 + 0.1 * rs.randn(Cout)).astype(np.float32))
+    shift = torch.from_numpy((0.1 * rs.randn(Cout)).astype(np.float32))
+    up = torch.nn.functional.interpolate(x.double(), size=(OH, OW), mode="bilinear", align_corners=True)
+    want = torch.relu(torch.nn.functional.conv2d(up, w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    wt = w.permute(2, 3, 0, 1).reshape(9 * Cout, Cin, 1, 1).contiguous()
+    z = torch.nn.functional.conv2d(x.cuda(), wt.cuda())
+    out = ops.upconv3x3_gather(z, scale.cuda(), shift.cuda(), Cout, (OH, OW), ops.ACT_RELU)
+    assert (out.cpu().double() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 32, 32), (1, 256, 512, 32, 32), (3, 512, 128, 8, 32), (2, 128, 256, 5, 64)])
 def test_conv3x3_bf16x3_vs_fp32_conv(ops, B, Cin, Cout, H, W):
     """Split-bf16 MFMA implicit GEMM vs the fp64 convolution on the CPU; error bound 3*2^-18 * sum|w x| per output
