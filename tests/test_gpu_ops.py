@@ -329,6 +329,21 @@ def test_dgrad_weight_pack_equals_pack_of_flipped_transposed_filter(ops, Cout, C
     assert got.shape == want.shape and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,C,n,K", [(1, 8, 64, 5), (2, 6, 33, 20), (1, 4, 50, 16)])
+def test_att_pool_backward_any_k(ops, B, C, n, K):
+    """Att_pooling's softmax . feature . sum over K and its backward for K other than 16 (the general kernels; K = 16 has its own),
+    against autograd through the oracle's formulation in fp64."""
+    g = torch.Generator(device="cpu").manual_seed(K * 10 + n)
+    att = (torch.randn(B, C, n, K, generator=g) * 2).cuda().requires_grad_(True)
+    feat = torch.randn(B, C, n, K, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(B, C, n, generator=g).cuda()
+    (ops.att_pool(att, feat) * w).sum().backward()
+    a64, f64 = att.detach().double().requires_grad_(True), feat.detach().double().requires_grad_(True)
+    ((torch.softmax(a64, dim=3) * f64).sum(3) * w.double()).sum().backward()
+    assert (att.grad.double() - a64.grad).abs().max().item() < 1e-5 * max(1.0, a64.grad.abs().max().item())
+    assert (feat.grad.double() - f64.grad).abs().max().item() < 1e-5 * max(1.0, f64.grad.abs().max().item())
+
+
 def test_gather_backward_matches_autograd(ops):
     from oracle import ops_ref
     rs = np.random.RandomState(6)
@@ -389,6 +404,21 @@ def test_match_vs_oracle(ops, prec, B, N, M):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
+def test_match_more_than_64_model_panels(ops, prec):
+    """M > 16384 model vertices (more panels than the LDS-panel kernel's grid takes): the tiled kernel + split merge, same contract."""
+    from oracle import ops_ref
+    N, M = 300, 16384 + 700
+    scene, model = _desc(np.random.RandomState(7), 1, N, M)
+    gi, gv, gs = ops.match(scene.cuda(), model.cuda(), precision=prec, return_sim=True)
+    gi2, gv2 = ops.match(scene.cuda(), model.cuda(), precision=prec)
+    wv, wi, ws = ops_ref.match_argmax(scene[0], model)
+    assert (gs[0].cpu() - ws).abs().max().item() < 1e-4 and (gv[0].cpu() - wv).abs().max().item() < 1e-4
+    at_got = ws.gather(1, gi[0].cpu().long().unsqueeze(1)).squeeze(1)
+    assert ((wv - at_got) < 1e-4).all()
+    assert torch.equal(gi, gi2) and torch.equal(gv, gv2) and torch.equal(gs.max(dim=2)[0], gv)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
 def test_match_first_max_on_exact_ties(ops, prec):
     """Duplicate model vertices give exactly equal similarities: the lowest index must win (torch.max CPU)."""
     rs = np.random.RandomState(0)
@@ -427,6 +457,30 @@ def test_seg_mask(ops):
         want = ops_ref.seg_mask(seg[b])
         assert torch.equal(mask[b].cpu().bool(), want)
         assert count[b].item() == int(want.sum())
+
+
+def test_seg_mask_more_than_65536_points(ops):
+    """N > 65536 points per crop: the grid-wide kernel with an atomic count (the per-crop workgroup form covers the product's sizes)."""
+    from oracle import ops_ref
+    rs = np.random.RandomState(11)
+    seg = torch.from_numpy(rs.randn(2, 2, 70001).astype(np.float32))
+    mask, count = ops.seg_mask(seg.cuda())
+    for b in range(2):
+        want = ops_ref.seg_mask(seg[b])
+        assert torch.equal(mask[b].cpu().bool(), want) and count[b].item() == int(want.sum())
+
+
+def test_mfma_probes_run(ops):
+    """The two measurement probes behind tools/mfma_probe.py (gdm_mfma_probe_hip, gdm_mfma_probe_lds_hip) launch and finish."""
+    from geometric_aware_dense_matching_amd import _lib
+    sink = torch.zeros(64 * 512, device="cuda")
+    L = _lib.lib()
+    assert L.gdm_mfma_probe_hip(64, 30, 1, sink.data_ptr(), None) == 0
+    assert L.gdm_mfma_probe_hip(64, 30, 3, sink.data_ptr(), None) == 0
+    for rpu in (1, 2, 4):
+        assert L.gdm_mfma_probe_lds_hip(64, 16, rpu, sink.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert L.gdm_mfma_probe_hip(64, 31, 1, sink.data_ptr(), None) != 0      # iters must be a multiple of 3: refused, not launched
 
 
 def test_pointops_ballquery_fps(ops):
@@ -543,6 +597,68 @@ def test_upconv3x3_gather_other_scale_factors(ops, B, Cin, Cout, H, W, OH, OW):
     z = torch.nn.functional.conv2d(x.cuda(), wt.cuda())
     out = ops.upconv3x3_gather(z, scale.cuda(), shift.cuda(), Cout, (OH, OW), ops.ACT_RELU)
     assert (out.cpu().double() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,H,W,OH,OW", [(2, 3, 16, 16, 20, 20), (1, 2, 9, 12, 12, 31), (2, 4, 8, 8, 16, 16)])
+def test_upconv3x3_gather_train_forward_backward_any_scale(ops, B, C, H, W, OH, OW):
+    """The differentiable 9-tap gather (training form of PSPUpsample) and its backward for x2 AND other scale factors (the backward's
+    direct kernel), against autograd through bilinear resize + shifted sums in fp64."""
+    g = torch.Generator(device="cpu").manual_seed(OH + OW)
+    z = torch.randn(B, 9 * C, H, W, generator=g).cuda().requires_grad_(True)
+    bias = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(B, C, OH, OW, generator=g).cuda()
+    out = ops.upconv3x3_gather_train(z, bias, C, (OH, OW))
+    (out * w).sum().backward()
+    z64, b64 = z.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    up = torch.nn.functional.interpolate(z64, size=(OH, OW), mode="bilinear", align_corners=True).view(B, 9, C, OH, OW)
+    pad = torch.nn.functional.pad(up, (1, 1, 1, 1))
+    ref = sum(pad[:, ky * 3 + kx, :, ky:ky + OH, kx:kx + OW] for ky in range(3) for kx in range(3)) + b64.view(1, -1, 1, 1)
+    (ref * w.double()).sum().backward()
+    tol = lambda t: 1e-5 * max(1.0, t.abs().max().item())
+    assert (out.double() - ref).abs().max().item() < tol(ref)
+    assert (z.grad.double() - z64.grad).abs().max().item() < tol(z64.grad)
+    assert (bias.grad.double() - b64.grad).abs().max().item() < 1e-4 * max(1.0, b64.grad.abs().max().item())
+
+
+def test_spline_scalar_kernels_for_odd_channel_counts(ops):
+    """SplineConv with a channel count that is not a multiple of 4 takes the one-channel-per-thread kernels (the 16-byte forms need
+    C % 4 == 0 and 512 % C == 0): the direct first layer against the dense form, and gdm_spline_pairs_aggregate_hip against its
+    definition out_i = mean_e sum_s basis[e,s] Y[pos[e,s]] + root_i + bias."""
+    from geometric_aware_dense_matching_amd import _lib, splinecnn
+    torch.manual_seed(4)
+    M, C = 700, 10
+    pos3 = torch.rand(M, 3, device="cuda")
+    ei, ea = splinecnn.build_mesh_graph(pos3, k=4)
+    order = torch.argsort(ei[1], stable=True)
+    rowptr = torch.zeros(M + 1, dtype=torch.int32, device="cuda")
+    rowptr[1:] = torch.cumsum(torch.bincount(ei[1][order], minlength=M), 0).to(torch.int32)
+    src, attr = ei[0][order].to(torch.int32).contiguous(), ea[order].contiguous()
+    conv = splinecnn.SplineConv(9, C).cuda()
+    conv.bias.data.normal_(0, 0.1)
+    x = torch.randn(M, 9, device="cuda")
+    with torch.enable_grad():
+        dense = conv(x, rowptr, src, attr, relu=True).detach()
+    with torch.no_grad():
+        direct = conv(x, rowptr, src, attr, relu=True)
+    assert (dense - direct).abs().max().item() < 1e-5 * max(1.0, dense.abs().max().item())
+    # pair aggregation, C = 10
+    E = int(rowptr[-1])
+    R = 5000
+    g = torch.Generator(device="cpu").manual_seed(9)
+    Y = torch.randn(R, C, generator=g).cuda()
+    pos = torch.randint(0, R, (E, 8), generator=g).int().cuda()
+    basis = torch.rand(E, 8, generator=g).cuda()
+    root = torch.randn(M, C, generator=g).cuda()
+    out = torch.empty(M, C, device="cuda")
+    rc = _lib.lib().gdm_spline_pairs_aggregate_hip(Y.data_ptr(), rowptr.data_ptr(), pos.data_ptr(), basis.data_ptr(), root.data_ptr(),
+                                                   conv.bias.data_ptr(), M, C, 1, out.data_ptr(), None)
+    assert rc == 0
+    msg = (basis.double().unsqueeze(2) * Y.double()[pos.long()]).sum(1)                   # [E, C]
+    tgt = torch.repeat_interleave(torch.arange(M, device="cuda"), (rowptr[1:] - rowptr[:-1]).long())
+    acc = torch.zeros(M, C, dtype=torch.float64, device="cuda").index_add_(0, tgt, msg)
+    deg = (rowptr[1:] - rowptr[:-1]).double().clamp(min=1).unsqueeze(1)
+    want = torch.relu(acc / deg + root.double() + conv.bias.double())
+    assert (out.double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 32, 32), (1, 256, 512, 32, 32), (3, 512, 128, 8, 32), (2, 128, 256, 5, 64)])
