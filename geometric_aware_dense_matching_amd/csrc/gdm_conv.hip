@@ -26,7 +26,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int ROWB = 512;                 // bytes per packed row (128 channels, hi | lo)
-constexpr int CV_THREADS = 512;           // 8 waves
 constexpr int CV_PIX = 256;               // pixels per workgroup (32 per wave)
 constexpr int CV_CO = 128;                // output channels per workgroup
 constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
@@ -38,9 +37,6 @@ constexpr int CV_PANEL = CV_CO * ROWB;    // 64 KiB
 #endif
 #ifndef GDM_CONV_GLDS
 #define GDM_CONV_GLDS 1                  // 1: weight panels of the 16x16x32 kernel by LDS-DMA (eight-wave workgroups); 0: through registers
-#endif
-#ifndef GDM_CONV_EXP
-#define GDM_CONV_EXP 0                   // development: 1 = no weight staging / barrier after panel 0, 2 = no operand reloads (wrong results)
 #endif
 
 __device__ __forceinline__ void split8(const float* v, unsigned (&hi)[4], unsigned (&lo)[4])
@@ -117,238 +113,6 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
 }
 
 __device__ __forceinline__ int swz(int col, int ch) { return col * ROWB + (((ch & 16) | ((ch ^ col) & 15)) << 4); }
-
-// TAPS 1 = 1x1 convolution / plain GEMM (centre tap only); NKS = k-steps of 16 channels per chunk (4: a single 64-channel chunk)
-template <int ACT, bool HAS_RES, int TAPS = 9, bool PIXMAJOR = false, int NKS = 8>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_bf16x3_kernel(const unsigned char* __restrict__ xpk, const unsigned char* __restrict__ wpk,
-                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                    const float* __restrict__ res, int B, int Cin, int Cout, int H, int W,
-                                                                    float* __restrict__ out,
-                                                                    // grouped / gathered GEMM (TAPS 1, PIXMAJOR): row r of the product reads packed
-                                                                    // pixel rowidx[r] and every 256-row tile has its own 128 output channels
-                                                                    // [tile_co0[tile], +128) of the packed weights; the tile is stored 128 wide
-                                                                    const int32_t* __restrict__ rowidx = nullptr,
-                                                                    const int32_t* __restrict__ tile_co0 = nullptr,
-                                                                    // NCHW form only: the result ALSO (or only, out == nullptr) as the
-                                                                    // next convolution's packed operand (planes of [B, Cout] at H x W)
-                                                                    unsigned char* __restrict__ outpk = nullptr)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x CV_PANEL
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, h = lane >> 5;
-    const int nchunk = (Cin + 127) / 128;
-    const int npanel = TAPS * nchunk;
-    const int hw = H * W;
-    const long ptot = rowidx ? (long)B : (long)B * hw;             // grouped form: B carries the number of product rows
-    const long pix0 = (long)blockIdx.x * CV_PIX + wave * 32;       // this wave's first pixel (32 consecutive, same image row: W % 32 == 0)
-    const int co0 = tile_co0 ? tile_co0[blockIdx.x] : blockIdx.y * CV_CO;
-    const long pc = min(pix0, ptot - 32);
-    const int b = (int)(pc / hw);
-    const int prem = (int)(pc - (long)b * hw);
-    const int y = prem / W, x0 = prem - y * W;
-    // this lane's pixel (b, y, x0 + lr) at tap (0,0) inside a plane of the packed activations: padded coords (y + ky, x + kx)
-    const long plane = (long)(H + 2) * (W + 2);
-    const long pixbase = rowidx ? (long)max(rowidx[min(pix0, ptot - 32) + lr], 0) : (long)y * (W + 2) + x0 + lr;
-
-    // A operand: 8 k-steps x (hi, lo) fragments = 64 VGPRs, single-buffered.  The loop is k-step major (12 MFMAs over the
-    // four 32-channel output blocks per k-step), so a k-step's registers are dead right after it and are reloaded with the
-    // NEXT panel's data there and then -- except the last two k-steps, whose reload waits for the top of the next iteration:
-    // hipcc drains vmcnt to 0 at a loop back-edge for loads consumed in the next iteration, so nothing may be issued late in
-    // the body (a load issued just before the back-edge exposes its whole latency to all 8 waves at once).
-    u32x4 ahi[8], alo[8];                                           // fragments of k-step s: ahi[s], alo[s]
-    // Panel order: chunk-major, the nine taps of a 128-channel chunk back to back (GDM_CONV_TAP_INNER, default).  The activation
-    // operand of a chunk is re-read once per tap; tap-major order puts nchunk panels (~1.3 MB per XCD each) between two reads of the
-    // same planes, more than the XCD's 4 MB L2 holds at nchunk = 4 -- every re-read then came from beyond L2 (PMC round 3: 406 MB
-    // fetched for 81 MB of operands) with that latency in front of the panel's first MFMA.
-    auto panel_tc = [&](int it, int& tap, int& chunk) {
-        if (TAPS == 1) { tap = 4; chunk = it; }
-        else if (GDM_CONV_TAP_INNER) { chunk = it / TAPS; tap = it - chunk * TAPS; }
-        else { tap = it / nchunk; chunk = it - tap * nchunk; }
-    };
-    auto a_row = [&](int it) {
-        int tap, chunk;
-        panel_tc(it, tap, chunk);
-        const int ky = tap / 3, kx = tap - ky * 3;
-        return xpk + (((long)((rowidx ? 0 : b) * nchunk + chunk) * 32 + h) * plane + pixbase + (long)ky * (W + 2) + kx) * 16;
-    };
-    const long fstride = 2 * plane * 16;                            // fragment 2*ss+h -> 2*(ss+1)+h
-    auto load_a = [&](const unsigned char* r, int ss) {
-        ahi[ss] = *reinterpret_cast<const u32x4*>(r + ss * fstride);
-        alo[ss] = *reinterpret_cast<const u32x4*>(r + (8 + ss) * fstride);
-    };
-    u32x4 stage[8];
-    auto stage_load = [&](int it) {                                 // 128 rows x 32 chunks = 4096 chunks, 8 per thread
-        int tap, chunk;
-        panel_tc(it, tap, chunk);
-        const int wit = (TAPS == 1) ? it : tap * nchunk + chunk;   // the packed weights stay (tap, chunk, co) rows
-        const unsigned char* src = wpk + ((long)wit * ((Cout + 127) & ~127) + co0) * ROWB;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = i * CV_THREADS + tid;
-            stage[i] = *reinterpret_cast<const u32x4*>(src + (long)g * 16);
-        }
-    };
-    auto stage_store = [&](int buf) {
-        unsigned char* base = smem + buf * CV_PANEL;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = i * CV_THREADS + tid;
-            *reinterpret_cast<u32x4*>(base + swz(g >> 5, g & 31)) = stage[i];
-        }
-    };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-
-#ifndef GDM_CONV_LATE
-#define GDM_CONV_LATE 2
-#endif
-    constexpr int LATE = NKS == 8 ? GDM_CONV_LATE : 1;                                         // k-steps whose reload is deferred to the next iteration's top
-    stage_load(0);
-    stage_store(0);
-    {
-        const unsigned char* r0 = a_row(0);
-#pragma unroll
-        for (int ss = 0; ss < NKS - LATE; ++ss) load_a(r0, ss);
-    }
-    for (int it = 0; it < npanel; ++it) {
-        if (!(GDM_CONV_EXP & 1) || it == 0) __syncthreads();       // panel `it` is in LDS; panel it-1's readers are done
-        const bool more = it + 1 < npanel;
-        const unsigned char* rcur = a_row(it);
-        const unsigned char* rnext = a_row(more ? it + 1 : it);
-        const unsigned char* base = smem + ((GDM_CONV_EXP & 1) ? 0 : (it & 1)) * CV_PANEL;
-        // 16 units of (k-step s, output-block pair p): 6 MFMAs on this unit's fragments while the next unit's four fragment
-        // reads are in flight
-        // fragments of unit u live in ring slot u % (PF + 1); PF units' reads are in flight while a unit's MFMAs issue
-#ifndef GDM_CONV_PF
-#define GDM_CONV_PF 2
-#endif
-        constexpr int PF = GDM_CONV_PF;
-        constexpr int NU = 2 * NKS;
-        u32x4 fh[PF + 1][2], fl[PF + 1][2];
-        auto frag_load = [&](int un) {
-            const int sn = un >> 1, pn = un & 1, slot = un % (PF + 1);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                fh[slot][j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 2 * sn + h));
-                fl[slot][j] = *reinterpret_cast<const u32x4*>(base + swz((2 * pn + j) * 32 + lr, 16 + 2 * sn + h));
-            }
-        };
-#pragma unroll
-        for (int un = 0; un < PF; ++un) frag_load(un);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int s = u >> 1, pr = u & 1, slot = u % (PF + 1);
-            if (u + PF < NU) frag_load(u + PF);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[s]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, alo[s]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fl[slot][j]), acc[2 * pr + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, fh[slot][j]), acc[2 * pr + j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2 * pr + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, fh[slot][j]), acc[2 * pr + j], 0, 0, 0);
-            if (pr == 1 && s < NKS - LATE && !(GDM_CONV_EXP & 2)) load_a(rnext, s);          // (a harmless re-read of the same rows on the last panel)
-            if (u == 0) {
-                // issued BEHIND the first MFMAs: the wait hipcc puts in front of them for the loop-carried operand registers
-                // is a vmcnt(0), and must not find this iteration's loads already in flight
-                if (more && !(GDM_CONV_EXP & 1)) stage_load(it + 1);
-                if (!(GDM_CONV_EXP & 2) || it == 0) {
-#pragma unroll
-                    for (int ss = NKS - LATE; ss < NKS; ++ss) load_a(rcur, ss);
-                }
-            }
-            // one scheduling region per unit (the scheduler otherwise regroups the MFMAs accumulator-major, which pulls the
-            // late operand loads to the front); inside it: MFMA : ds_read 1:1, the operand reloads behind the MFMAs
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u + PF < NU && i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more && !(GDM_CONV_EXP & 1)) stage_store((it + 1) & 1);
-    }
-
-    // ---- epilogue: lane = output channel (col), registers = pixels; 4 consecutive pixels per register quad -> 16-B stores ----
-    if (pix0 >= ptot) return;
-    if (PIXMAJOR) {
-        // out[pixel][co]: for one register (pixel) the 32 lanes of a half-wave hold 32 consecutive channels = 128 B
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int co = co0 + cb * 32 + lr;
-            if (co >= Cout) continue;
-            const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-            const int ocol = tile_co0 ? cb * 32 + lr : co;          // grouped form: a compact CV_CO-wide row per product row
-            const int ostride = tile_co0 ? CV_CO : Cout;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const long pix = pix0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float v = acc[cb][reg] * sc + sh;
-                if (ACT == 1) v = fmaxf(v, 0.f);
-                out[pix * ostride + ocol] = v;
-            }
-        }
-        return;
-    }
-    // Packed output: the tile goes through LDS (the weight panels are dead) to turn "lane = channel, registers = pixels" into
-    // "lane = pixel, 8 consecutive channels = one 16-byte fragment", is split to bf16 hi / lo there and stored into the planes of
-    // the next layer's operand: 32 consecutive pixels x 16 B = 512-B runs.  Saves that layer's pack kernel and, when the fp32 map
-    // has no other reader, the fp32 store.
-    constexpr int TSTRIDE = 132;                                     // floats per pixel row of the wave's tile (128 + 4: conflict-free reads)
-    float* tl = reinterpret_cast<float*>(smem) + wave * 32 * TSTRIDE;
-    if (outpk) __syncthreads();                                      // every wave has finished reading the last weight panel
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int co = co0 + cb * 32 + lr;
-        const bool live = co < Cout;
-        const float sc = (live && scale) ? scale[co] : 1.f, sh = (live && shift) ? shift[co] : 0.f;
-        float* op = out ? out + ((long)b * Cout + (live ? co : 0)) * hw + prem : nullptr;
-        const float* rp = (HAS_RES && live) ? res + ((long)b * Cout + co) * hw + prem : nullptr;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int poff = 8 * g + 4 * h;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[cb][4 * g + j] * sc + sh;
-            if (HAS_RES && live) {
-                const float4 r4 = *reinterpret_cast<const float4*>(rp + poff);
-                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-            }
-            if (ACT == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (op && live) *reinterpret_cast<float4*>(op + poff) = make_float4(v[0], v[1], v[2], v[3]);
-            if (outpk) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tl[(poff + j) * TSTRIDE + cb * 32 + lr] = live ? v[j] : 0.f;
-            }
-        }
-    }
-    if (outpk) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int ochunks = (Cout + 127) / 128;
-        const int ochunk = co0 / 128;
-        unsigned char* ob = outpk + (((long)(b * ochunks + ochunk) * 32) * plane + (long)(y + 1) * (W + 2) + x0 + lr + 1) * 16;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int q = 2 * it + h;                                // 8-channel group of this workgroup's 128 channels
-            if (co0 + q * 8 >= Cout) continue;
-            const float4 a0 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(tl + lr * TSTRIDE + q * 8 + 4);
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            unsigned hi[4], lo[4];
-            split8(v, hi, lo);
-            *reinterpret_cast<uint4*>(ob + (long)q * plane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            *reinterpret_cast<uint4*>(ob + (long)(16 + q) * plane * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same kernel on v_mfma_f32_16x16x32_bf16.  Same workgroup tile (256 pixels x 128 output channels), same panels, same LDS
@@ -443,7 +207,7 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
 
     u32x4 ahi[NS][NPH], alo[NS][NPH];                               // fragments of k-step S, pixel fragment ph
     // Panel bookkeeping in scalar registers, advanced by counters (no division in the loop): panel = (chunk, ky, kx), chunk-major
-    // (GDM_CONV_TAP_INNER, see conv3x3_bf16x3_kernel) or tap-major.  pan_a / pan_w: byte offsets of a panel's operand rows / weight rows.
+    // (GDM_CONV_TAP_INNER) or tap-major.  pan_a / pan_w: byte offsets of a panel's operand rows / weight rows.
     struct Pan { int chunk, ky, kx; };
     auto pan_next = [&](Pan p) -> Pan {
         if (TAPS == 1) { ++p.chunk; return p; }
@@ -686,17 +450,9 @@ __global__ __launch_bounds__(MF_THREADS) void conv_mfma16_kernel(const unsigned 
     }
 }
 
-// which MFMA shape the conv / GEMM entry points launch (GDM_CONV_SHAPE=32 keeps v_mfma_f32_32x32x16_bf16)
-#ifndef GDM_CONV_SHAPE
-#define GDM_CONV_SHAPE 16
-#endif
-#if GDM_CONV_SHAPE == 16
+// (the v_mfma_f32_32x32x16_bf16 form of rounds 1-3, `conv3x3_bf16x3_kernel`, was removed in round 4: compiled, never launched)
 #define CONV_KERNEL conv_mfma16_kernel
 constexpr int CONV_THREADS = MF_THREADS, CONV_WPIX = MF_WPIX, CONV_SMEM = MF_SMEM;
-#else
-#define CONV_KERNEL conv3x3_bf16x3_kernel
-constexpr int CONV_THREADS = CV_THREADS, CONV_WPIX = 32, CONV_SMEM = 2 * CV_PANEL > 8 * 32 * 132 * 4 ? 2 * CV_PANEL : 8 * 32 * 132 * 4;
-#endif
 
 } // namespace
 
@@ -872,7 +628,7 @@ extern "C" int gdm_conv3x3_strided_hip(const void* xpk, const void* wpk, const f
 static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
                           int B, int Cin, int Cout, int H, int W, int stride, int act, float* out, void* outpk, void* stream)
 {
-    GDM_CHECK_ARG(stride == 1 || (stride == 2 && GDM_CONV_SHAPE == 16), "gdm_conv3x3: stride=%d (1, or 2 on the 16x16x32 kernel)", stride);
+    GDM_CHECK_ARG(stride == 1 || stride == 2, "gdm_conv3x3: stride=%d (1 or 2)", stride);
     GDM_CHECK_ARG(xpk && wpk && (out || outpk), "gdm_conv3x3_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv3x3_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
     GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CONV_WPIX == 0,
@@ -896,12 +652,7 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
         (void)hipFuncSetAttribute((const void*)CONV_KERNEL<1, true, 9, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr = true;
     }
-#if GDM_CONV_SHAPE == 16
 #define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk, stride)
-#else
-#define CV(A, R, NK) hipLaunchKernelGGL((CONV_KERNEL<A, R, 9, false, NK>), grid, dim3(CONV_THREADS), SMEM, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, res, B, Cin, Cout, H, W, out, (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)outpk)
-#endif
-#if GDM_CONV_SHAPE == 16
     // 64-channel tiles where 128-channel ones leave the chip half empty (or pad a 64-channel layer with zero rows): twice the workgroups
     if (narrow_tiles(grid.x, Cout)) {
         constexpr int SMEM4 = 2 * 64 * ROWB > CV_PIX * 68 * 4 ? 2 * 64 * ROWB : CV_PIX * 68 * 4;
@@ -928,7 +679,7 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
             else { if (res) CV4H(1, true); else CV4H(1, false); }
 #undef CV4H
 #undef AT4H
-            return gdm_launch_status("conv3x3_bf16x3_kernel (64-channel tiles, 128 pixels)");
+            return gdm_launch_status("conv_mfma16_kernel (3x3, 64-channel tiles, 128 pixels)");
         }
         if (Cin == 64) {
             if (act == 0) { if (res) CV4(0, true, 4); else CV4(0, false, 4); }
@@ -939,9 +690,8 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
         }
 #undef CV4
 #undef AT4
-        return gdm_launch_status("conv3x3_bf16x3_kernel (64-channel tiles)");
+        return gdm_launch_status("conv_mfma16_kernel (3x3, 64-channel tiles)");
     }
-#endif
     if (Cin == 64) {                                             // one half-filled chunk: only its four non-zero k-steps are run
         if (act == 0) { if (res) CV(0, true, 4); else CV(0, false, 4); }
         else { if (res) CV(1, true, 4); else CV(1, false, 4); }
@@ -950,7 +700,7 @@ static int conv3x3_launch(const void* xpk, const void* wpk, const float* scale, 
         else { if (res) CV(1, true, 8); else CV(1, false, 8); }
     }
 #undef CV
-    return gdm_launch_status("conv3x3_bf16x3_kernel");
+    return gdm_launch_status("conv_mfma16_kernel (3x3)");
 }
 
 extern "C" int gdm_conv3x3_packed_hip(const void* xpk, const void* wpk, const float* scale, const float* shift, const float* res,
@@ -994,7 +744,6 @@ extern "C" int gdm_conv1x1_packed_hip(const void* xpk, const void* wpk, const fl
 extern "C" int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long w_bstride, int B, int Cin, int Cout, int H, int W, float* out,
                                          void* stream)
 {
-#if GDM_CONV_SHAPE == 16
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_wb_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && Cin >= 128 && Cin % 128 == 0 && Cout >= 1, "gdm_conv1x1_packed_wb_hip: Cin=%d Cout=%d (Cin a multiple of 128)", Cin, Cout);
     GDM_CHECK_ARG(W % 32 == 0 && H >= 1 && (H * W) % CV_PIX == 0, "gdm_conv1x1_packed_wb_hip: W=%d must be a multiple of 32 and H*W=%d of %d",
@@ -1011,10 +760,6 @@ extern "C" int gdm_conv1x1_packed_wb_hip(const void* xpk, const void* wpk, long 
                        (const unsigned char*)wpk, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, B, Cin, Cout, H, W, out,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, 1, w_bstride);
     return gdm_launch_status("conv1x1_bf16x3_kernel (per-image weights)");
-#else
-    gdm_set_error("gdm_conv1x1_packed_wb_hip: built without the 16x16x32 kernel");
-    return GDM_EINVAL;
-#endif
 }
 
 // H, W = OUTPUT size; xpk = the (H stride) x (W stride) input (the downsample branch of a strided residual block reads every other pixel)
@@ -1027,7 +772,7 @@ extern "C" int gdm_conv1x1_strided_hip(const void* xpk, const void* wpk, const f
 static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, const float* shift,
                           int B, int Cin, int Cout, int H, int W, int stride, int act, int pixel_major, float* out, void* stream)
 {
-    GDM_CHECK_ARG(stride == 1 || (stride == 2 && GDM_CONV_SHAPE == 16), "gdm_conv1x1: stride=%d (1, or 2 on the 16x16x32 kernel)", stride);
+    GDM_CHECK_ARG(stride == 1 || stride == 2, "gdm_conv1x1: stride=%d (1 or 2)", stride);
     GDM_CHECK_ARG(xpk && wpk && out, "gdm_conv1x1_packed_hip: NULL pointer");
     GDM_CHECK_ARG(B >= 1 && cin_ok(Cin) && Cout >= 1, "gdm_conv1x1_packed_hip: Cin=%d Cout=%d (Cin a multiple of 128, or 64)", Cin, Cout);
     GDM_CHECK_ARG(Cin != 64 || !pixel_major, "gdm_conv1x1_packed_hip: Cin=64 is built for the NCHW output only");
@@ -1036,7 +781,6 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
     GDM_CHECK_ARG(act == 0 || act == 1, "gdm_conv1x1_packed_hip: act=%d", act);
     const long ptot = (long)B * H * W;
     const unsigned ptiles = gdm_cdiv(ptot, CV_PIX);
-#if GDM_CONV_SHAPE == 16
     // 144-channel tiles (nine 16-channel blocks) where they divide Cout and fill the chip's rounds better than 128-channel ones: the
     // tap GEMMs of PSPUpsample have 9 * Cout' outputs -- 2304 at 64 pixel tiles = 1152 tiles of 128 (4.5 rounds of 256 CUs, paid as
     // 5) or 1024 tiles of 144 (4 rounds); 576 at 256 pixel tiles = 1280 tiles of 128, the last of every five half empty, or 1024 of 144
@@ -1058,8 +802,7 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
             return gdm_launch_status("conv1x1_bf16x3_kernel (144-channel tiles)");
         }
     }
-#endif
-    const bool narrow = (GDM_CONV_SHAPE == 16) && Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
+    const bool narrow = Cin != 64 && !pixel_major && narrow_tiles(ptiles, Cout);
     const unsigned ctiles = gdm_cdiv(Cout, narrow ? 64 : CV_CO);    // the last block's rows beyond Cout are zero weights, never stored
     // pixel tiles are the fast grid axis: workgroups that share a pixel tile land on one XCD.  (Channel tiles fastest was measured on the
     // 1024 -> 2304 tap GEMM in round 3: same time, 903 MB instead of 573 MB of fabric traffic -- each XCD then streams every weight panel.)
@@ -1076,17 +819,12 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
         attr = true;
     }
     if (Cin == 64) {                                            // one half-filled chunk: only its four non-zero k-steps are run
-#if GDM_CONV_SHAPE == 16
 #define C1TAIL , (const int32_t*)nullptr, (const int32_t*)nullptr, (unsigned char*)nullptr, stride
-#else
-#define C1TAIL
-#endif
 #define C1H(A) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, false, 4>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
         if (act == 0) C1H(0); else C1H(1);
 #undef C1H
         return gdm_launch_status("conv1x1_bf16x3_kernel");
     }
-#if GDM_CONV_SHAPE == 16
     if (narrow) {
         const dim3 grid4 = grid;
         static bool attr4 = false;
@@ -1100,7 +838,6 @@ static int conv1x1_launch(const void* xpk, const void* wpk, const float* scale, 
 #undef C14
         return gdm_launch_status("conv1x1_bf16x3_kernel (64-channel tiles)");
     }
-#endif
 #define C1(A, P) hipLaunchKernelGGL((CONV_KERNEL<A, false, 1, P>), grid, dim3(CONV_THREADS), 2 * CV_PANEL, s, (const unsigned char*)xpk, (const unsigned char*)wpk, scale, shift, (const float*)nullptr, B, Cin, Cout, H, W, out C1TAIL)
     if (act == 0) { if (pixel_major) C1(0, true); else C1(0, false); }
     else { if (pixel_major) C1(1, true); else C1(1, false); }

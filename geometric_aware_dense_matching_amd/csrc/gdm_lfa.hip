@@ -41,180 +41,14 @@ struct LfaArgs {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// PP = points per thread group: a thread (slot, channel c) walks PP points, so every weight it loads (Wf[jj][c], Wm[jj][c]) feeds PP
-// points' FMAs.  PP = 1 is what ships (PP = 2 at the deep levels was measured slower, see gdm_lfa_stage_hip).
-template <int D, int PP>
-__global__ __launch_bounds__(256) void lfa_stage_kernel(const LfaArgs a)
-{
-    constexpr int H = D / 2;
-    constexpr int P = (256 / D) * PP;                  // points per workgroup
-    __shared__ __attribute__((aligned(16))) float fcat[P][D][LK];
-    __shared__ __attribute__((aligned(16))) float fx1[P][H][LK];
-    __shared__ float pe[P][10][LK];
-    __shared__ int nidx[P][LK];
-    __shared__ float aggv[P][D];
-
-    const int tid = threadIdx.x;
-    const int slot = tid / D, c = tid - slot * D;
-    const int b = blockIdx.y;
-    const int n = a.n;
-    const float slope = a.slope;
-    int pidx[PP];                                      // point of (slot, pp), clamped; live = inside the crop
-    bool live[PP];
-#pragma unroll
-    for (int pp = 0; pp < PP; ++pp) {
-        const int raw = (int)blockIdx.x * P + slot * PP + pp;
-        live[pp] = raw < n;
-        pidx[pp] = min(raw, n - 1);
-    }
-
-    // 1. relative position encoding of the 16 neighbours (rel_pos_enc_kernel's arithmetic)
-    if (c < LK) {
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            const int p = slot * PP + pp, i = pidx[pp];
-            int jn = a.idx[((long)b * n + i) * LK + c];
-            jn = min(max(jn, 0), n - 1);
-            const float* pi = a.xyz + ((long)b * n + i) * 3;
-            const float* pj = a.xyz + ((long)b * n + jn) * 3;
-            const float ax = pi[0], ay = pi[1], az = pi[2];
-            const float bx = pj[0], by = pj[1], bz = pj[2];
-            const float rx = __fsub_rn(ax, bx), ry = __fsub_rn(ay, by), rz = __fsub_rn(az, bz);
-            float s = __fmul_rn(rx, rx);
-            s = __fadd_rn(s, __fmul_rn(ry, ry));
-            s = __fadd_rn(s, __fmul_rn(rz, rz));
-            pe[p][0][c] = __fsqrt_rn(s);
-            pe[p][1][c] = rx; pe[p][2][c] = ry; pe[p][3][c] = rz;
-            pe[p][4][c] = ax; pe[p][5][c] = ay; pe[p][6][c] = az;
-            pe[p][7][c] = bx; pe[p][8][c] = by; pe[p][9][c] = bz;
-            nidx[p][c] = jn;
-        }
-    }
-    __syncthreads();
-
-    // 2. mlp1 on the encoding and the neighbour gather: thread (j, half of K) fills 8 entries of each
-    const int j = c % H, kb = (c / H) * 8;
-    {
-        float w[10];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) w[q] = a.w1t[q * H + j];
-        const float sc = a.s1[j], sh = a.b1[j];
-        const float* frow = a.feat + ((long)b * H + j) * n;
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            const int p = slot * PP + pp;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int k = kb + kk;
-                float v = 0.f;
-#pragma unroll
-                for (int q = 0; q < 10; ++q) v = fmaf(w[q], pe[p][q][k], v);
-                v = lrelu(fmaf(v, sc, sh), slope);
-                if (a.w2t) fx1[p][j][k] = v;
-                else fcat[p][H + j][k] = v;
-#if defined(GDM_LFA_EXP) && (GDM_LFA_EXP & 1)
-                fcat[p][j][k] = (a.feat + (long)b * H * n)[(long)nidx[p][k] * H + j];   // development: the access pattern of a point-major feature array (wrong values)
-#else
-                fcat[p][j][k] = frow[nidx[p][k]];
-#endif
-            }
-        }
-    }
-    __syncthreads();
-    if (a.w2t) {                                        // second stage: mlp2 on the encoded positions
-        float acc[PP][8];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp)
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) acc[pp][kk] = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < H; ++q) {
-            const float w = a.w2t[q * H + j];
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                const int p = slot * PP + pp;
-                const float4 f0 = *reinterpret_cast<const float4*>(&fx1[p][q][kb]);
-                const float4 f1 = *reinterpret_cast<const float4*>(&fx1[p][q][kb + 4]);
-                acc[pp][0] = fmaf(w, f0.x, acc[pp][0]); acc[pp][1] = fmaf(w, f0.y, acc[pp][1]);
-                acc[pp][2] = fmaf(w, f0.z, acc[pp][2]); acc[pp][3] = fmaf(w, f0.w, acc[pp][3]);
-                acc[pp][4] = fmaf(w, f1.x, acc[pp][4]); acc[pp][5] = fmaf(w, f1.y, acc[pp][5]);
-                acc[pp][6] = fmaf(w, f1.z, acc[pp][6]); acc[pp][7] = fmaf(w, f1.w, acc[pp][7]);
-            }
-        }
-        const float sc = a.s2[j], sh = a.b2[j];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp)
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) fcat[slot * PP + pp][H + j][kb + kk] = lrelu(fmaf(acc[pp][kk], sc, sh), slope);
-        __syncthreads();
-    }
-
-    // 3. attention logits of channel c for the 16 neighbours: att[k] = sum_j Wf[c][j] * fcat[j][k]
-    float att[PP][LK];
-#pragma unroll
-    for (int pp = 0; pp < PP; ++pp)
-#pragma unroll
-        for (int k = 0; k < LK; ++k) att[pp][k] = 0.f;
-#pragma unroll 4
-    for (int jj = 0; jj < D; ++jj) {
-        const float w = a.wft[jj * D + c];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            const float4* fr = reinterpret_cast<const float4*>(&fcat[slot * PP + pp][jj][0]);
-            const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3];
-            float (&t)[LK] = att[pp];
-            t[0] = fmaf(w, f0.x, t[0]); t[1] = fmaf(w, f0.y, t[1]); t[2] = fmaf(w, f0.z, t[2]); t[3] = fmaf(w, f0.w, t[3]);
-            t[4] = fmaf(w, f1.x, t[4]); t[5] = fmaf(w, f1.y, t[5]); t[6] = fmaf(w, f1.z, t[6]); t[7] = fmaf(w, f1.w, t[7]);
-            t[8] = fmaf(w, f2.x, t[8]); t[9] = fmaf(w, f2.y, t[9]); t[10] = fmaf(w, f2.z, t[10]); t[11] = fmaf(w, f2.w, t[11]);
-            t[12] = fmaf(w, f3.x, t[12]); t[13] = fmaf(w, f3.y, t[13]); t[14] = fmaf(w, f3.z, t[14]); t[15] = fmaf(w, f3.w, t[15]);
-        }
-    }
-    // 4. softmax over K, feature * score, sum over K
-#pragma unroll
-    for (int pp = 0; pp < PP; ++pp) {
-        const int p = slot * PP + pp;
-        float (&t)[LK] = att[pp];
-        float mx = t[0];
-#pragma unroll
-        for (int k = 1; k < LK; ++k) mx = fmaxf(mx, t[k]);
-        float den = 0.f;
-#pragma unroll
-        for (int k = 0; k < LK; ++k) {
-            t[k] = __expf(t[k] - mx);                      // v_exp_f32 path (arguments <= 0): ~1 ulp, far inside the 1e-4 budget
-            den += t[k];
-        }
-        const float rden = 1.0f / den;
-        float num = 0.f;
-#pragma unroll
-        for (int k = 0; k < LK; ++k) num = fmaf(fcat[p][c][k], t[k] * rden, num);
-        aggv[p][c] = num;
-    }
-    __syncthreads();
-
-    // 5. mlp on the pooled feature: out[c] = lrelu(sm[c] * sum_j Wm[c][j] agg[j] + bm[c])
-    const int OUT = a.OUT;
-    if (c < OUT) {
-        float o[PP];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) o[pp] = 0.f;
-#pragma unroll 8
-        for (int jj = 0; jj < D; ++jj) {
-            const float w = a.wmt[jj * OUT + c];
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) o[pp] = fmaf(w, aggv[slot * PP + pp][jj], o[pp]);
-        }
-        const float sm = a.sm[c], bm = a.bm[c];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp)
-            if (live[pp]) a.out[((long)b * OUT + c) * n + pidx[pp]] = lrelu(fmaf(o[pp], sm, bm), slope);
-    }
-}
-
+// (Rounds 1-2 ran the stage as `lfa_stage_kernel`, thread = (point, channel) with every product as fp32 FMAs on broadcast LDS reads,
+// 35-63 us per launch; it stayed behind GDM_LFA_MFMA=0 as an A/B leg until round 4 and was removed with that switch: no caller or test
+// reached it.  The phases the MFMA kernel below did not change -- position encoding, mlp1 + gather, the final mlp -- are written out in it.)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same stage with its two large products -- mlp2 (d/2 x d/2 per neighbour) and the attention logits (d x d per neighbour) -- on
-// v_mfma_f32_16x16x4_f32 (exact fp32 products).  In the FMA form above every thread reads the whole d x 16 block of its point from
-// LDS (four 16-byte broadcast reads per 16 FMAs): the stage is bound by LDS issue, 35-63 us per launch for ~1 GFLOP.  Here a tile is
+// v_mfma_f32_16x16x4_f32 (exact fp32 products).  In the FMA form every thread read the whole d x 16 block of its point from
+// LDS (four 16-byte broadcast reads per 16 FMAs): the stage was bound by LDS issue, 35-63 us per launch for ~1 GFLOP.  Here a tile is
 // 16 channels x the 16 neighbours of one point:
 //   A fragment (block in LDS):   lane l = neighbour l & 15, input row j + (l >> 4)                     (256 contiguous bytes, conflict-free)
 //   B fragment (W^T [in][out]):  lane l = output channel c0 + (l & 15), input row j + (l >> 4)         (global, 64-byte runs)
@@ -359,11 +193,7 @@ __global__ __launch_bounds__(256) void lfa_stage_mfma_kernel(const LfaArgs a)
                 v = lrelu(fmaf(v, sc, sh), slope);
                 if (a.w2t) fx1[p][j][k] = v;
                 else fcat[p][H + j][k] = v;
-#if defined(GDM_LFA_EXP) && (GDM_LFA_EXP & 1)
-                fcat[p][j][k] = (a.feat + (long)b * H * n)[(long)nidx[p][k] * H + j];   // development: the access pattern of a point-major feature array (wrong values)
-#else
                 fcat[p][j][k] = frow[nidx[p][k]];
-#endif
             }
         }
     }
@@ -450,34 +280,18 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && n >= 1, "gdm_lfa_stage_hip: bad shape");
     LfaArgs a{xyz, idx, feat, w1t, s1, b1, w2t, s2, b2, wft, wmt, sm, bm, out, n, OUT, slope};
     hipStream_t s = (hipStream_t)stream;
-    // points per thread group: 1.  GDM_LFA_PP=2 (development) lets a thread walk two points at D = 128 / 256 so that every weight load
-    // feeds two points: measured SLOWER (71 -> 82 us and 75 -> 120 us per block of two stages at batch 16): the deep levels have
-    // 2048 / 512 points in all, and halving the workgroups costs more than the shared loads save
-    // default: the MFMA form at every level, one point per thread group at D = 32 / 64 and two above (GDM_LFA_MFMA=0: the FMA form
-    // everywhere; = D0 > 1: the MFMA form from D0 up -- the A/B switch of tools/bench_lfa.py).  Per block of two stages at batch 16 (tools/bench_lfa.py, FMA -> MFMA): 109 -> 96, 82 -> 69, 70 -> 60, 73 -> 60 us;
-    // whole step (eager / hipGraph replay, one box): FMA at D = 32 only 3.830 / 3.957 ms, MFMA everywhere 3.807 / 3.942 ms
-    static const int mf_env = getenv("GDM_LFA_MFMA") ? atoi(getenv("GDM_LFA_MFMA")) : 1;
-    if (mf_env && D >= (mf_env > 1 ? mf_env : 32)) {
-        const int pp = D <= 64 ? 1 : 2;
-        const int P = (256 / D) * pp;
-        dim3 g(gdm_cdiv(n, P), B);
+    // the MFMA form at every level, one point per thread group at D = 32 / 64 and two above (two points per group at the deep levels
+    // for the FMA phases was measured slower: 71 -> 82 us and 75 -> 120 us per block of two stages at batch 16).  Per block of two
+    // stages at batch 16 (FMA form of rounds 1-2 -> this): 109 -> 96, 82 -> 69, 70 -> 60, 73 -> 60 us
+    const int pp = D <= 64 ? 1 : 2;
+    const int P = (256 / D) * pp;
+    dim3 g(gdm_cdiv(n, P), B);
 #define GDM_LFA_MF(DD) do { if (pp == 1) hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 1>), g, dim3(256), 0, s, a); \
                             else hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 2>), g, dim3(256), 0, s, a); } while (0)
-        if (D == 32) GDM_LFA_MF(32);
-        else if (D == 64) GDM_LFA_MF(64);
-        else if (D == 128) GDM_LFA_MF(128);
-        else GDM_LFA_MF(256);
+    if (D == 32) GDM_LFA_MF(32);
+    else if (D == 64) GDM_LFA_MF(64);
+    else if (D == 128) GDM_LFA_MF(128);
+    else GDM_LFA_MF(256);
 #undef GDM_LFA_MF
-        return gdm_launch_status("lfa_stage_mfma_kernel");
-    }
-    const int PP = 1;
-    const int P = (256 / D) * PP;
-    dim3 grid(gdm_cdiv(n, P), B);
-    if (D == 32) hipLaunchKernelGGL((lfa_stage_kernel<32, 1>), dim3(gdm_cdiv(n, 8), B), dim3(256), 0, s, a);
-    else if (D == 64) hipLaunchKernelGGL((lfa_stage_kernel<64, 1>), dim3(gdm_cdiv(n, 4), B), dim3(256), 0, s, a);
-    else if (D == 128 && PP == 2) hipLaunchKernelGGL((lfa_stage_kernel<128, 2>), grid, dim3(256), 0, s, a);
-    else if (D == 128) hipLaunchKernelGGL((lfa_stage_kernel<128, 1>), dim3(gdm_cdiv(n, 2), B), dim3(256), 0, s, a);
-    else if (PP == 2) hipLaunchKernelGGL((lfa_stage_kernel<256, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((lfa_stage_kernel<256, 1>), dim3(gdm_cdiv(n, 1), B), dim3(256), 0, s, a);
-    return gdm_launch_status("lfa_stage_kernel");
+    return gdm_launch_status("lfa_stage_mfma_kernel");
 }

@@ -1,11 +1,7 @@
-// PSPUpsample(64 -> 64) = Upsample(x2, bilinear, align_corners) + Conv3x3 + BN + PReLU (models/cnn/pspnet.py:34-45) in ONE kernel, gfx950.
-//
-// conv3x3(up(x)) is computed as in upconv3x3_gather (gdm_image.hip): per tap a LOW-resolution channel mix z_tap = W_tap . x, then
-// a 9-tap bilinear gather.  For the last up stage (128x128 -> 256x256, batch 16) the 9*64-channel z tensor is 604 MB that the
-// two-kernel form writes and reads back.  Here a workgroup owns a 16x16 output tile of one image: it loads the <= 11x11 source
-// patch of x (64 channels) once, splits it to bf16 hi/lo in LDS, forms z for 16 output channels at a time on the matrix cores
-// (split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate, the scheme of the matching / convolution kernels) into LDS and gathers
-// from there.  z never reaches HBM; the price is the halo (121 / 64 patch pixels per tile).
+// PSPUpsample(64 -> 64) = Upsample(x2, bilinear, align_corners) + Conv3x3 + BN + PReLU (models/cnn/pspnet.py:34-45) in ONE kernel, gfx950:
+// the dense form (`upconv_tile64_kernel`: the upsampled tile built in LDS, nine tap products on the matrix cores), the sampled-pixel form
+// of the last image stage (`upconv_final_points_kernel`) and the 64-channel fusion tail (`conv64_gather_add_act_mfma_kernel`).  All use
+// split-bf16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate: the scheme of the matching / convolution kernels).
 #include "gdm_common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -18,25 +14,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int UF_C = 64;                 // channels in and out
-constexpr int UF_T = 16;                 // output tile edge
-constexpr int UF_PW = 11;                // patch row stride (and maximum patch edge)
-constexpr int UF_PX = 128;               // patch pixels padded to 4 MFMA row blocks
-constexpr int UF_G = 8;                  // output channels per pass
-constexpr int UF_ZR = 9 * UF_G;          // z rows per pass (tap, channel)
-constexpr int UF_ZP = 129;               // z row stride in floats (odd: conflict-free column writes)
 constexpr int UF_ROWB = 256;             // packed row: 64 bf16 hi | 64 bf16 lo
-constexpr int UF_XS = UF_PX * UF_ROWB;                   // 32 KiB
-constexpr int UF_NCB = (UF_ZR + 31) / 32;                // MFMA column blocks per pass (3: 96 columns for 72 z rows)
-constexpr int UF_WS = UF_NCB * 32 * UF_ROWB;             // 24 KiB
-constexpr int UF_ZS = (UF_ZR * UF_ZP + 32) * 4;          // 37.3 KiB (+ slack: the gather always reads the +1 column / +1 row neighbours)
-// the x patch is dead once every wave holds its A fragments, so z re-uses its space: 61 KiB per workgroup, two per CU
-constexpr int UF_R0 = UF_ZS > UF_XS ? UF_ZS : UF_XS;
-#ifndef UF_NOALIAS
-constexpr int UF_ALIAS_OFF = 0;
-#else
-constexpr int UF_ALIAS_OFF = UF_XS;
-#endif
-constexpr int UF_LDS = UF_ALIAS_OFF + UF_R0 + UF_WS;
 
 __device__ __forceinline__ unsigned short bf16_rne(float v) { return gdm_bf16_1(v); }
 __device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -58,149 +36,8 @@ __global__ __launch_bounds__(256) void upconv_pack_w_kernel(const float* __restr
     r[64 + ci] = lo;
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void upconv_fused64_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             int H, int W, int OH, int OW, float rh, float rw, float slope,
-                                                             float* __restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xs = smem;                                   // phase A only
-    float* zs = reinterpret_cast<float*>(smem + UF_ALIAS_OFF);  // passes (aliases xs unless UF_ALIAS_OFF)
-    unsigned char* ws = smem + UF_ALIAS_OFF + UF_R0;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int ox_t = blockIdx.x * UF_T, oy_t = blockIdx.y * UF_T;
-    // source window of the tile incl. the one-pixel ring the 3x3 taps reach and the +1 bilinear neighbour
-    const int ys0 = min((int)(rh * (float)max(oy_t - 1, 0)), H - 1);
-    const int ys1 = min((int)(rh * (float)min(oy_t + UF_T, OH - 1)) + 1, H - 1);
-    const int xs0 = min((int)(rw * (float)max(ox_t - 1, 0)), W - 1);
-    const int xs1 = min((int)(rw * (float)min(ox_t + UF_T, OW - 1)) + 1, W - 1);
-    const int ph = ys1 - ys0 + 1, pw = xs1 - xs0 + 1;             // <= UF_PW each (checked on the host for the scale factors)
-
-    // ---- A: the patch of x, split to bf16 hi / lo, one packed row per patch pixel ----
-    const float* xb = x + (long)b * UF_C * H * W;
-    {
-        constexpr int NE = (UF_C * UF_PW * UF_PW + 255) / 256;       // 31 elements per thread: all loads are issued before any is used
-        float v[NE];
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i;
-            const int ci = e / (UF_PW * UF_PW), q = e - ci * (UF_PW * UF_PW);
-            const int r = q / UF_PW, c = q - r * UF_PW;
-            v[i] = (e < UF_C * UF_PW * UF_PW && r < ph && c < pw) ? xb[((long)ci * H + ys0 + r) * W + xs0 + c] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i;
-            if (e < UF_C * UF_PW * UF_PW) {
-                const int ci = e / (UF_PW * UF_PW), q = e - ci * (UF_PW * UF_PW);
-                const unsigned short hi = bf16_rne(v[i]), lo = bf16_rne(v[i] - bf16_f32(hi));
-                *reinterpret_cast<unsigned short*>(xs + uf_off(q, ci >> 3) + (ci & 7) * 2) = hi;
-                *reinterpret_cast<unsigned short*>(xs + uf_off(q, 8 + (ci >> 3)) + (ci & 7) * 2) = lo;
-            }
-        }
-    }
-    // rows 121..127 of xs are never read back through z (no output samples them) but feed the MFMAs: keep them finite
-    for (int e = tid; e < (UF_PX - UF_PW * UF_PW) * 16; e += 256) {
-        const int q = UF_PW * UF_PW + (e >> 4), ch = e & 15;
-        *reinterpret_cast<u32x4*>(xs + uf_off(q, ch)) = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    // ---- per-thread gather geometry: output pixel (oy, ox), for each tap the patch index of its top-left corner and the 4 weights ----
-    const int ty = tid >> 4, tx = tid & 15;
-    const int oy = oy_t + ty, ox = ox_t + tx;
-    const bool live = oy < OH && ox < OW;
-    int q00[9];                              // the +1 column / +1 row neighbours always exist in the padded patch (weight 0 at the image edge)
-    float w00[9], w01[9], w10[9], w11[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
-        const bool ok = live && yy >= 0 && yy < OH && xx >= 0 && xx < OW;
-        const float sy = rh * (float)min(max(yy, 0), OH - 1), sx = rw * (float)min(max(xx, 0), OW - 1);
-        const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        q00[tap] = (y0 - ys0) * UF_PW + (x0 - xs0);
-        const float m = ok ? 1.f : 0.f;                        // taps outside the (upsampled) image contribute zero padding
-        w00[tap] = m * (1.f - ly) * (1.f - lx);
-        w01[tap] = m * (1.f - ly) * lx;
-        w10[tap] = m * ly * (1.f - lx);
-        w11[tap] = m * ly * lx;
-    }
-    __syncthreads();
-
-    // A fragments of this wave's 32 patch pixels: 4 k-steps x (hi, lo), kept for all four passes
-    u32x4 ah[4], al[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        ah[s] = *reinterpret_cast<const u32x4*>(xs + uf_off(wave * 32 + lr, 2 * s + h));
-        al[s] = *reinterpret_cast<const u32x4*>(xs + uf_off(wave * 32 + lr, 8 + 2 * s + h));
-    }
-
-    for (int g = 0; g < UF_C / UF_G; ++g) {
-        // ---- B: weight rows (tap, g*G + j) -> ws row tap*G + j; rows beyond 9*G duplicate the last one (their z is never stored) ----
-        for (int e = tid; e < UF_NCB * 32 * 16; e += 256) {
-            const int row = e >> 4, ch = e & 15;
-            const int rr = min(row, UF_ZR - 1);
-            const int tap = rr / UF_G, j = rr - tap * UF_G;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wpk + ((long)(tap * UF_C + g * UF_G + j)) * UF_ROWB + ch * 16);
-            *reinterpret_cast<u32x4*>(ws + uf_off(row, ch)) = v;
-        }
-        __syncthreads();                                           // ws ready; previous pass's gather is done with zs
-
-        // ---- z[32 pixels of this wave][(tap, channel) columns] on the matrix cores ----
-#pragma unroll
-        for (int cb = 0; cb < UF_NCB; ++cb) {
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const int n = cb * 32 + lr;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + uf_off(n, 2 * s + h)));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + uf_off(n, 8 + 2 * s + h)));
-                const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[s]);
-                const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc, 0, 0, 0);
-            }
-            if (n < UF_ZR) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int px = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    zs[n * UF_ZP + px] = acc[reg];
-                }
-            }
-        }
-        __syncthreads();                                           // zs complete
-
-        // ---- 9-tap bilinear gather of the channels of this pass ----
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < UF_G; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float* zr = zs + (tap * UF_G + j) * UF_ZP + q00[tap];
-                    acc = fmaf(w00[tap], zr[0], acc);
-                    acc = fmaf(w01[tap], zr[1], acc);
-                    acc = fmaf(w10[tap], zr[UF_PW], acc);
-                    acc = fmaf(w11[tap], zr[UF_PW + 1], acc);
-                }
-                const int co = g * UF_G + j;
-                float o = fmaf(acc, scale[co], shift[co]);
-                if (ACT == 1) o = fmaxf(o, 0.f);
-                if (ACT == 2) o = o > 0.f ? o : o * slope;
-                out[(((long)b * UF_C + co) * OH + oy) * OW + ox] = o;
-            }
-        }
-        // the next pass overwrites ws before its barrier and zs after it: all reads of zs must be done first
-        __syncthreads();
-    }
-}
+// (the z-gather form of rounds 1-2, `upconv_fused64_kernel`, and its GDM_UPCONV_FUSED64=gather switch were removed in round 4: the
+// direct form below replaced it and no test or caller reached it)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Direct form: the workgroup builds the UPSAMPLED tile (8 x 16 output pixels + the one-pixel ring the 3x3 taps reach, 64 channels,
@@ -744,12 +581,7 @@ extern "C" int gdm_upconv_fused64_hip(const float* x, const void* wpk, const flo
     GDM_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && OH >= 1 && OW >= 1 && act >= 0 && act <= 2, "gdm_upconv_fused64_hip: bad shape");
     const float rh = uf_scale_ac(H, OH), rw = uf_scale_ac(W, OW);
     hipStream_t s = (hipStream_t)stream;
-    static int form = -1;                                         // GDM_UPCONV_FUSED64=gather: the z-gather kernel (development A/B)
-    if (form < 0) {
-        const char* e = getenv("GDM_UPCONV_FUSED64");
-        form = (e && !strcmp(e, "gather")) ? 1 : 0;
-    }
-    if (form == 0) {
+    {
         // worst-case source window of a tile edge: (edge + 1) output steps of size r, + the +1 neighbour, + rounding
         GDM_CHECK_ARG((int)(rh * (UT_TY + 1)) + 3 <= UT_PH && (int)(rw * (UT_TX + 1)) + 3 <= UT_PWV,
                       "gdm_upconv_fused64_hip: scale factors %g x %g need a source patch larger than %dx%d", rh, rw, UT_PH, UT_PWV);
@@ -767,21 +599,6 @@ extern "C" int gdm_upconv_fused64_hip(const float* x, const void* wpk, const flo
         else hipLaunchKernelGGL(upconv_tile64_kernel<2>, gt, dim3(256), UT_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
         return gdm_launch_status("upconv_tile64_kernel");
     }
-    // worst-case source window of a 16-pixel tile edge: (16 + 1) output steps of size r, + the +1 neighbour, + rounding
-    GDM_CHECK_ARG((int)(rh * (UF_T + 1)) + 3 <= UF_PW && (int)(rw * (UF_T + 1)) + 3 <= UF_PW,
-                  "gdm_upconv_fused64_hip: scale factors %g x %g need a source patch larger than %dx%d", rh, rw, UF_PW, UF_PW);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)upconv_fused64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, UF_LDS);
-        (void)hipFuncSetAttribute((const void*)upconv_fused64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, UF_LDS);
-        (void)hipFuncSetAttribute((const void*)upconv_fused64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, UF_LDS);
-        attr = true;
-    }
-    dim3 grid(gdm_cdiv(OW, UF_T), gdm_cdiv(OH, UF_T), B);
-    if (act == 0) hipLaunchKernelGGL(upconv_fused64_kernel<0>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
-    else if (act == 1) hipLaunchKernelGGL(upconv_fused64_kernel<1>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
-    else hipLaunchKernelGGL(upconv_fused64_kernel<2>, grid, dim3(256), UF_LDS, s, x, (const unsigned char*)wpk, scale, shift, H, W, OH, OW, rh, rw, slope, out);
-    return gdm_launch_status("upconv_fused64_kernel");
 }
 
 extern "C" int gdm_pack_rows64_hip(const float* w, int R, void* out, void* stream)

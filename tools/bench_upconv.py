@@ -1,5 +1,5 @@
 """PSPUpsample(64 -> 64) kernel alone at the last up stage's shape (batch 16, 128^2 -> 256^2).  Development aid.
-GDM_UPCONV_FUSED64=gather selects the z-gather form for an A/B."""
+(The z-gather form it could be compared with, GDM_UPCONV_FUSED64=gather, was removed in round 4.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,4 +30,4 @@ b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / n * 1e3
 fl = 2.0 * B * 4 * H * H * 64 * 64 * 9
 print("form %s: %.1f us; %.0f GB/s of in+out; %.0f TF/s bf16 issued at output resolution" %
-      (os.environ.get("GDM_UPCONV_FUSED64", "tile"), us, (B * 64 * H * H * 4 * 5) / us / 1e3, 3 * fl / us / 1e6))
+      ("tile", us, (B * 64 * H * H * 4 * 5) / us / 1e3, 3 * fl / us / 1e6))
