@@ -286,12 +286,9 @@ extern "C" int gdm_lfa_stage_hip(const float* xyz, const int32_t* idx, const flo
     const int pp = D <= 64 ? 1 : 2;
     const int P = (256 / D) * pp;
     dim3 g(gdm_cdiv(n, P), B);
-#define GDM_LFA_MF(DD) do { if (pp == 1) hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 1>), g, dim3(256), 0, s, a); \
-                            else hipLaunchKernelGGL((lfa_stage_mfma_kernel<DD, 2>), g, dim3(256), 0, s, a); } while (0)
-    if (D == 32) GDM_LFA_MF(32);
-    else if (D == 64) GDM_LFA_MF(64);
-    else if (D == 128) GDM_LFA_MF(128);
-    else GDM_LFA_MF(256);
-#undef GDM_LFA_MF
+    if (D == 32) hipLaunchKernelGGL((lfa_stage_mfma_kernel<32, 1>), g, dim3(256), 0, s, a);
+    else if (D == 64) hipLaunchKernelGGL((lfa_stage_mfma_kernel<64, 1>), g, dim3(256), 0, s, a);
+    else if (D == 128) hipLaunchKernelGGL((lfa_stage_mfma_kernel<128, 2>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lfa_stage_mfma_kernel<256, 2>), g, dim3(256), 0, s, a);
     return gdm_launch_status("lfa_stage_mfma_kernel");
 }

@@ -648,9 +648,6 @@ extern "C" int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float*
     a.total = (long)B * n;
     const long tiles = (a.total + PT - 1) / PT;
     GDM_CHECK_ARG(tiles <= 0x7fffffffL, "gdm_pointwise_hip: grid too large");
-    // enough 64 x 64 tiles to fill the chip: four waves per workgroup, no K split.  Otherwise sixteen waves per workgroup share the
-    // K axis: 8 parts of two 16-channel groups (2x the workgroups) where K is deep, else 4 parts of four channel groups
-    const long base = tiles * gdm_cdiv(Cout, 64);
     hipStream_t st = (hipStream_t)stream;
     bool vec = (n % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)wt & 15) == 0) && !w_rowmajor;      // (the FMA form's 16-byte weight loads run along Cout)
     for (int s = 0; s < nseg; ++s) vec = vec && !segs[s].idx && (((uintptr_t)segs[s].x & 15) == 0);
@@ -660,8 +657,7 @@ extern "C" int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float*
         if (vec) hipLaunchKernelGGL((pointwise_kernel<NW, KS, true>), grid, dim3(NW * 64), 0, st, a);                               \
         else hipLaunchKernelGGL((pointwise_kernel<NW, KS, false>), grid, dim3(NW * 64), 0, st, a);                                  \
     } while (0)
-    static const int mfma_env = getenv("GDM_PW_MFMA") ? atoi(getenv("GDM_PW_MFMA")) : 1;
-    if (mfma_env && a.K >= 32 && gdm_cdiv(Cout, 16) <= 65535) {
+    if (a.K >= 32 && gdm_cdiv(Cout, 16) <= 65535) {
         // K parts per tile: as many as leave each wave >= 16 rows, at most 8 (= waves of the workgroup)
         int ks = 1;
         while (ks < 8 && a.K / (2 * ks) >= 16 && tiles * gdm_cdiv(Cout, 16) * ks < 4096) ks *= 2;
@@ -690,10 +686,9 @@ extern "C" int gdm_pointwise2_hip(const gdm_pw_seg* segs, int nseg, const float*
 #undef GDM_PWM
         return gdm_launch_status("pointwise_mfma_kernel");
     }
+    // K < 32 (or more than 2^20 output channels): the FMA form, four waves per 64 x 64 tile, no K split
     GDM_CHECK_ARG(nseg <= 3, "gdm_pointwise_hip: four segments need K >= 32 (the MFMA form)");
-    if (base >= 256 || a.K < 64) GDM_PW_LAUNCH(4, 1, 64);
-    else if (a.K >= 256 && gdm_cdiv(Cout, 16) <= 65535) GDM_PW_LAUNCH(8, 8, 16);
-    else GDM_PW_LAUNCH(8, 2, 64);
+    GDM_PW_LAUNCH(4, 1, 64);
 #undef GDM_PW_LAUNCH
     return gdm_launch_status("pointwise_kernel");
 }

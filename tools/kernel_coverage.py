@@ -19,6 +19,28 @@ with open(sys.argv[1]) as fh:
         base = re.sub(r"<.*", "", base).strip()
         if base in counts:
             counts[base] += calls
+# instance level: the library's kernel symbols (host-side launch stubs, demangled) against the launched names
+import subprocess
+so = os.path.join(root, "geometric_aware_dense_matching_amd", "libgdm_hip.so")
+syms = [l.split()[-1] for l in subprocess.run(["nm", so], capture_output=True, text=True).stdout.splitlines() if "__device_stub__" in l]
+dem = subprocess.run(["c++filt"], input="\n".join(sorted(set(syms))), capture_output=True, text=True).stdout.splitlines()
+
+
+def norm(n):
+    n = n.replace("__device_stub__", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", n).strip()
+
+
+instances = sorted(set(norm(d) for d in dem))
+launched = set()
+with open(sys.argv[1]) as fh:
+    for row in csv.DictReader(fh):
+        launched.add(norm(row.get("Name") or ""))
+inst_never = [i for i in instances if i not in launched]
+print("%d template instances in the library, %d launched by the suite, %d never:" % (len(instances), len(instances) - len(inst_never), len(inst_never)))
+for i in inst_never:
+    print("  never launched: %s" % i)
+print()
 never = sorted(k for k, v in counts.items() if v == 0)
 print("%d kernels defined, %d launched by the suite, %d never:" % (len(counts), len(counts) - len(never), len(never)))
 for k in never:
