@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from geometric_aware_dense_matching_amd import ops, randla, settings
-rs = np.random.RandomState(0)
+rs = np.random.RandomState(int(os.environ.get("SEED", "0")))
+torch.manual_seed(int(os.environ.get("SEED", "0")))
 bad = 0
 def chk(name, ok, info):
     global bad
@@ -150,5 +151,31 @@ for it in range(8):                                              # 3x3 convoluti
     got = ops.conv3x3_bf16x3(x, ops.conv3x3_pack_weight(w), 128)
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
     chk("conv_half_tiles", (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (B, H))
+# round 4: per-point layers in every dispatch form (FMA for K < 32, K-split MFMA, many-point channel-wave form), both weight layouts
+for it in range(30):
+    B, K, Co = rs.randint(1, 4), int(rs.choice([3, 9, 16, 32, 48, 64, 130, 256])), int(rs.choice([1, 8, 16, 24, 64, 100, 128]))
+    n = int(rs.choice([1, 7, 64, 1000, 4096, 30000, 70001]))
+    x = torch.randn(B, K, n, device="cuda"); w = torch.randn(Co, K, device="cuda") / K ** 0.5
+    sc = torch.rand(Co, device="cuda") + 0.5; sh = torch.randn(Co, device="cuda")
+    ref = torch.einsum("ok,bkn->bon", w.double(), x.double()) * sc.double()[None, :, None] + sh.double()[None, :, None]
+    ref = torch.where(ref > 0, ref, ref * 0.2)
+    a = ops.pointwise([x], w.t().contiguous(), sc, sh, ops.ACT_LEAKY, 0.2); b2 = ops.pointwise([x], w, sc, sh, ops.ACT_LEAKY, 0.2, w_rowmajor=True)
+    tol = 1e-5 * max(1.0, ref.abs().max().item())
+    chk("pointwise", (a.double() - ref).abs().max().item() < tol and (b2.double() - ref).abs().max().item() < tol, (B, K, Co, n))
+for it in range(12):                                             # input-gradient weight pack == pack of the flipped, transposed filter
+    Cout, Cin, taps = int(rs.choice([64, 128, 256])), rs.randint(1, 300), int(rs.choice([1, 9]))
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") if taps == 9 else torch.randn(Cout, Cin, device="cuda")
+    want = ops.conv3x3_pack_weight(w.flip(2, 3).transpose(0, 1).contiguous()) if taps == 9 else ops.gemm_pack_weight(w.t().contiguous())
+    chk("dgrad_pack", torch.equal(ops.conv_pack_weight_dgrad(w), want), (Cout, Cin, taps))
+for it in range(12):                                             # kNN on cell lists (unorganised supports of >= 1024 points, K = 16) incl. clustered data
+    B, S, Q = rs.randint(1, 4), int(rs.choice([1024, 1500, 2048, 5000, 9000])), rs.randint(1, 3000)
+    sup = torch.rand(B, S, 3, device="cuda"); q = torch.rand(B, Q, 3, device="cuda")
+    if it % 3 == 0: sup[:, : S // 2] = sup[:, : S // 2] * 0.01 + 0.5          # half of the support in one cell
+    if it % 4 == 0: q = sup[:, torch.randint(0, S, (Q,), device="cuda")]       # queries ON support points (zero distances, ties)
+    idx, d2 = ops.knn_batch(sup, q, 16, return_d2=True)
+    dm = ((q[:, :, None, :] - sup[:, None, :, :]) ** 2).sum(-1)
+    rv = torch.topk(dm, 16, dim=2, largest=False)[0]
+    got = torch.gather(dm, 2, idx.long())
+    chk("knn_cells", torch.allclose(got, rv, rtol=1e-5, atol=1e-7), (B, S, Q))
 torch.cuda.synchronize()
 print("fuzz done, mismatches:", bad)
