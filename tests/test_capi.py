@@ -62,3 +62,34 @@ def test_ops_refuse_cpu_tensors():
         ops.gather_max(torch.zeros(1, 2, 3), torch.zeros(1, 1, 1, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.match(torch.zeros(1, 128, 32), torch.zeros(128, 64))
+
+
+def _is_ptr(a):
+    return a is ctypes.c_void_p or hasattr(a, "contents") or (hasattr(a, "_type_") and not isinstance(a._type_, str))
+
+
+@pytest.mark.parametrize("mode", ["null", "zero", "negative"])
+def test_every_entry_point_refuses_degenerate_arguments(lib, mode):
+    """Every int-returning entry point with pointer arguments, called with (a) all pointers NULL, (b) valid host pointers and every
+    size 0, (c) every size -1: a nonzero return code and a message, no launch, no crash -- host-side validation comes before any HIP
+    call (which is also why this runs without a GPU)."""
+    from geometric_aware_dense_matching_amd import _lib
+    buf = (ctypes.c_char * 65536)()
+    p = ctypes.addressof(buf)
+    called = 0
+    for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+        if res is not ctypes.c_int or not any(_is_ptr(a) for a in args):
+            continue
+        vals = []
+        for a in args:
+            if _is_ptr(a):
+                vals.append(None if mode == "null" else (p if a is ctypes.c_void_p else ctypes.cast(p, a)))
+            elif a in (ctypes.c_float, ctypes.c_double):
+                vals.append(0.0)
+            else:
+                vals.append(-1 if mode == "negative" else 0)
+        rc = getattr(lib, name)(*vals)
+        assert rc != 0, "%s accepted %s arguments" % (name, mode)
+        assert len(lib.gdm_last_error()) > 0
+        called += 1
+    assert called >= 100
