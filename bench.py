@@ -12,10 +12,12 @@ Workload at N GPUs: BASELINE.json configs[1] per GPU (LineMOD obj_01, batch 16, 
 stream; pyramid / mesh branch / point branch forked onto side streams) and keeps the forked one only if it is bit-identical to the
 single-stream eager step on the box at hand -- the bench times whatever that logic kept (`config.launch`), and reports the other
 forms and the eager loop beside it (`launch_forms`).  Top-level extras on a 1-GPU run: `value_b32` (batch 32), `value_exact_f32`
-(strict fp32 products everywhere), `rooflines` (one entry per kernel family that dominates the step), `cpu_baseline`.
+(strict fp32 products everywhere), `value_from_host` (PCIe-inclusive: every step's batch copied from pinned host memory first -- never
+the metric), `rooflines` (one entry per kernel family that dominates the step), `cpu_baseline`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --gpus N ...            # starts N ranks itself (torch.distributed.run, one process per GPU, RCCL)
+    python bench.py --group-of-one          # one rank INSIDE an RCCL group: the N-rank code path rehearsed on a 1-GPU box
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 """
