@@ -400,7 +400,8 @@ def light_extras(torch, dev, args, model, N, M):
     def from_host():
         # PCIe-inclusive: the reference's loop hands the model HOST tensors (train_lm.py model_fn: `.cuda()` per batch).  The headline
         # starts with the batch resident in HBM (the bench contract); here every step first copies its batch from pinned host memory --
-        # (a) on the step's own stream, (b) the next batch's copy on a copy stream beside the current replay (two staging sets).
+        # (a) on the step's own stream, (b) the next batch's copy on a copy stream beside the current replay (two staging sets; what a
+        # server with a loader thread does).
         B = args.batch
         d = dev_batch(303, B)
         host = {k: v.cpu().pin_memory() for k, v in d.items()}
@@ -428,20 +429,24 @@ def light_extras(torch, dev, args, model, N, M):
                 for k, v in host.items():
                     stage[i % 2][k].copy_(v, non_blocking=True)
                 filled[i % 2].record(cs)
-        for e in taken:
-            e.record(main)
-        K = 12
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fill(0)
-        for i in range(K):
-            if i + 1 < K:
-                fill(i + 1)
-            main.wait_event(filled[i % 2])
-            gp(stage[i % 2])                                          # device-to-device into the graph's static inputs, then the replay
-            taken[i % 2].record(main)
-        torch.cuda.synchronize()
-        ms_over = (time.perf_counter() - t0) / K * 1e3
+        def pipelined(K):
+            for e in taken:
+                e.record(main)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fill(0)
+            for i in range(K):
+                if i + 1 < K:
+                    fill(i + 1)
+                main.wait_event(filled[i % 2])
+                for k, buf in gp.static_in.items():                   # device-to-device into the graph's static inputs ...
+                    buf.copy_(stage[i % 2][k], non_blocking=True)
+                taken[i % 2].record(main)                             # ... after which the staging set may be refilled
+                gp.graph.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / K * 1e3
+        pipelined(8)                                                  # (the copy stream's first use is slow)
+        ms_over = pipelined(40)
         out["from_host"] = {"bytes_per_batch": nbytes, "h2d_ms_per_batch": round(copy_ms, 3), "h2d_GBps": round(nbytes / copy_ms / 1e6, 1),
                             "serial": {"ms_per_step": round(ms_serial, 3), "crops_per_s": round(B / ms_serial * 1e3, 1)},
                             "overlapped": {"ms_per_step": round(ms_over, 3), "crops_per_s": round(B / ms_over * 1e3, 1)},
@@ -907,7 +912,9 @@ def main(argv=None):
         line["extras"] = ex
         line["value_b32"] = (ex.get("b32") or {}).get("crops_per_s")
         line["value_exact_f32"] = (ex.get("exact_f32") or {}).get("crops_per_s")
-        line["value_from_host"] = ((ex.get("from_host") or {}).get("serial") or {}).get("crops_per_s")   # PCIe-inclusive (copy, then replay), NOT the metric
+        fh = ex.get("from_host") or {}                             # PCIe-inclusive, NOT the metric: the better of the two copy placements
+        line["value_from_host"] = max([v.get("crops_per_s") for v in (fh.get("serial"), fh.get("overlapped")) if v and v.get("crops_per_s")] or [None],
+                                      key=lambda t: t or 0.0)
         try:
             line["rooflines"] = ([dict(line["roofline"], name="match materialised"), dict(line["roofline_fused"], name="match fused")]
                                  + kernel_rooflines(torch, dev, B, N))
