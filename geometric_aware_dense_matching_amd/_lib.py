@@ -238,6 +238,10 @@ def lib():
             raise RuntimeError(
                 "libgdm_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C geometric_aware_dense_matching_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # torch FIRST: PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) and the process must hold exactly one.  Loaded
+        # before torch, this library pulls in /opt/rocm's runtime instead, torch then brings its own, and the first launch from here
+        # fails with "no ROCm-capable device is detected" (build() followed by smoke() in one process did exactly that).
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol

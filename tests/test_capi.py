@@ -93,3 +93,16 @@ def test_every_entry_point_refuses_degenerate_arguments(lib, mode):
         assert len(lib.gdm_last_error()) > 0
         called += 1
     assert called >= 100
+
+
+def test_library_loads_behind_torch_hip_runtime():
+    """A process must hold ONE HIP runtime: torch's.  _lib.lib() imports torch before it loads libgdm_hip.so, so that a process which
+    reaches the library first (__graft_entry__.build() followed by smoke()) does not pull in /opt/rocm's runtime beside torch's --
+    which ended in "no ROCm-capable device is detected" at the first launch."""
+    import subprocess
+    import sys
+    code = ("import sys; from geometric_aware_dense_matching_amd import _lib; before = 'torch' in sys.modules; _lib.lib(); "
+            "print(before, 'torch' in sys.modules)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split()[-2:] == ["False", "True"]

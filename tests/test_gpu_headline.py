@@ -496,3 +496,14 @@ def test_forked_replays_with_alternating_batches_equal_eager(headline_model):
         if not ok:
             bad.append((r, names))
     assert not bad, "forked replays with alternating inputs differ from the eager step: %r" % (bad,)
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() followed by smoke() in ONE fresh process (the order in which the library and torch get loaded differs from
+    every other test's: see tests/test_capi.py::test_library_loads_behind_torch_hip_runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
