@@ -968,15 +968,18 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
     const float* xp = x + plane * hw;
     for (int i = threadIdx.x; i < hw; i += 256) tile[i] = xp[i];
     __syncthreads();
-    // 1 + 4 + 9 + 36 = 50 bins; lanes per bin in proportion to its area: 64 | 4x16 | 9x4 | 36x1 = 200 threads,
-    // each group a power-of-two run of consecutive lanes so a shuffle reduction finishes the bin
+    // 4 + 9 + 36 bins summed by runs of consecutive lanes (a power of two each: a shuffle reduction finishes the bin), sized so that no
+    // lane walks more than 18 elements of a 32 x 32 map: 4x16 | 9x8 | 36x2 = 208 threads; the single 1 x 1 bin is the sum of the four
+    // 2 x 2 bins (they partition the map when H and W are even; otherwise 64 lanes walk it).  Round 3 gave the 36 smallest bins one
+    // lane each: 36 dependent LDS adds were the workgroup's critical path.
+    __shared__ float quad[4];
     const int t = threadIdx.x;
+    const bool even = (H % 2 == 0) && (W % 2 == 0);
     int s, bi, gsz, gl;
     float* o;
-    if (t < 64) { s = 1; bi = 0; gsz = 64; gl = t; o = o1 + plane; }
-    else if (t < 128) { s = 2; bi = (t - 64) >> 4; gsz = 16; gl = (t - 64) & 15; o = o2 + plane * 4; }
-    else if (t < 164) { s = 3; bi = (t - 128) >> 2; gsz = 4; gl = (t - 128) & 3; o = o3 + plane * 9; }
-    else if (t < 200) { s = 6; bi = t - 164; gsz = 1; gl = 0; o = o6 + plane * 36; }
+    if (t < 64) { s = 2; bi = t >> 4; gsz = 16; gl = t & 15; o = o2 + plane * 4; }
+    else if (t < 136) { s = 3; bi = (t - 64) >> 3; gsz = 8; gl = (t - 64) & 7; o = o3 + plane * 9; }
+    else if (t < 208) { s = 6; bi = (t - 136) >> 1; gsz = 2; gl = (t - 136) & 1; o = o6 + plane * 36; }
     else { s = 1; bi = 0; gsz = 1; gl = 0; o = nullptr; }
     const int by = bi / s, bx = bi - by * s;
     const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
@@ -984,8 +987,7 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
     const int bw = x1 - x0, cnt = (y1 - y0) * bw;
     float acc = 0.f;
     if (o) {
-        // element i = gl, gl + gsz, ... of the bin in row-major order, walked WITHOUT a division per element (two integer divisions by
-        // a run-time width per element were most of this kernel: 39 -> 15 us at 16 x 512 planes of 32 x 32); same order, same sums
+        // element i = gl, gl + gsz, ... of the bin in row-major order, walked without a division per element
         int ry = gl / bw, rx = gl - ry * bw;
         for (int i = gl; i < cnt; i += gsz) {
             acc += tile[(y0 + ry) * W + x0 + rx];
@@ -998,6 +1000,19 @@ __global__ __launch_bounds__(256) void psp_pools_kernel(const float* __restrict_
         if (m < gsz) acc += other;
     }
     if (o && gl == 0) o[bi] = acc / (float)cnt;
+    if (even) {
+        if (t < 64 && gl == 0) quad[bi] = acc;
+        __syncthreads();
+        if (t == 0) o1[plane] = ((quad[0] + quad[1]) + (quad[2] + quad[3])) / (float)hw;
+    } else {
+        __syncthreads();                                            // (every lane is done with its bin)
+        if (t < 64) {
+            float a1 = 0.f;
+            for (int i = t; i < hw; i += 64) a1 += tile[i];
+            for (int m = 1; m < 64; m <<= 1) a1 += __shfl_xor(a1, m, 64);
+            if (t == 0) o1[plane] = a1 / (float)hw;
+        }
+    }
 }
 
 // Backward of the four pools in one pass: gin[y][x] = sum over the bins (of every size) that contain (y, x) of grad_bin / bin area.
