@@ -275,3 +275,16 @@ def test_wgrad_direct_every_block_shape(ops, Cout, Cin):
     want = torch.einsum("bop,bcp->oc", go.double(), x.double())
     assert (gw.double() - want).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
     assert (gb.double() - go.double().sum((0, 2))).abs().max().item() < 1e-4 * max(1.0, go.double().sum((0, 2)).abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,with_bias", [(2, 128, 128, True), (1, 40, 24, False), (2, 13, 9, True), (1, 8, 8, True)])
+def test_final_stage_at_several_sizes(ops, B, H, W, with_bias):
+    """`final` = Conv2d(64, 64, 1) + LogSoftmax(dim=1) (the thread-per-pixel kernel, hardware exp) against fp64 torch, with and without
+    bias, at the step's size and at ragged ones."""
+    g = _gen(H * W + with_bias)
+    x = torch.randn(B, 64, H, W, generator=g).cuda()
+    w = (torch.randn(64, 64, 1, 1, generator=g) / 8).cuda()
+    b = (torch.randn(64, generator=g) * 0.1).cuda() if with_bias else None
+    want = torch.log_softmax(torch.nn.functional.conv2d(x.double(), w.double(), b.double() if with_bias else None), dim=1)
+    got = ops.conv1x1_logsoftmax(x, w, b)
+    assert (got.double() - want).abs().max().item() < 2e-5
