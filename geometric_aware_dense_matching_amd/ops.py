@@ -1306,7 +1306,6 @@ def upconv_final_points(x_pm, hw, choose, wpk, scale, shift, act, slope, wf_pk, 
     return out
 
 
-_final_wt_cache = {}
 
 
 def stem_pack_weight(weight):
@@ -1353,11 +1352,14 @@ def conv1x1_logsoftmax(x, weight, bias):
     """log_softmax over channels of a 64->64 1x1 convolution, one pass (the `final` stage, pspnet.py:108-112). Inference only."""
     x = _dev(x, torch.float32, "x")
     B, C, H, W = x.shape
+    # W^T (the kernel reads 64 contiguous scalars per ci), cached ON the weight tensor: it lives and dies with it.  (A module-level dict
+    # keyed by id(weight) served a NEW tensor that got a dead one's id, address and version the old one's transpose: wrong output, found
+    # by a test that builds several weights in a row.)
     key = (weight._version, weight.data_ptr())
-    cache = _final_wt_cache.get(id(weight))
+    cache = getattr(weight, "_gdm_final_wt", None)
     if cache is None or cache[0] != key:
-        cache = (key, weight.detach().reshape(C, C).t().contiguous())      # W^T: the kernel reads 64 contiguous scalars per ci
-        _final_wt_cache[id(weight)] = cache
+        cache = (key, weight.detach().reshape(C, C).t().contiguous())
+        weight._gdm_final_wt = cache
     w = cache[1]
     out = torch.empty_like(x)
     check(_lib.lib().gdm_conv1x1_logsoftmax_hip(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
