@@ -40,3 +40,20 @@ def _built_artifacts():
     if not os.path.exists(oknn._ORACLE_SO):
         oknn.build(ref=True)
     yield
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poison_uninitialised_memory():
+    """GDM_TEST_POISON=1: every torch.empty() comes back filled with NaN (torch.utils.deterministic.fill_uninitialized_memory under
+    use_deterministic_algorithms(warn_only)): an output element a kernel does not write, or a workspace word it reads before writing,
+    then shows up as NaN in whatever the test compares.  An audit mode, off by default (the fills cost time)."""
+    if os.environ.get("GDM_TEST_POISON") != "1":
+        yield
+        return
+    import torch
+    import warnings
+    warnings.filterwarnings("ignore", message=".*does not have a deterministic implementation.*")
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    yield
+    torch.use_deterministic_algorithms(False)
